@@ -1,0 +1,134 @@
+/*
+ * w4a16.h - C ABI of libw4a16.so: AWQ 4-bit-weight x fp16-activation GEMM for
+ * AMD MI355X (gfx950).
+ *
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless a
+ * comment says otherwise.  No entry point allocates, frees or synchronises:
+ * each one enqueues its kernels on `stream` (a hipStream_t, NULL = the default
+ * stream) and returns, so all of them may be called under HIP graph capture.
+ * The current HIP device must be the one that owns the buffers.
+ *
+ * Tensor conventions (identical to the reference's AWQ tensors):
+ *   x        [M, K]       fp16, row-major, contiguous
+ *   qweight  [K, N/8]     int32; column 8c+j of row k is nibble {0,4,1,5,2,6,3,7}[j] of word c
+ *   qzeros   [K/G, N/8]   int32, same nibble order
+ *   scales   [K/G, N]     fp16
+ *   out      [M, N]       fp16
+ * w[k][n] = fp16((q[k][n] - z[k/G][n]) * s[k/G][n]), one rounding, exactly as
+ * the reference dequantises; products accumulate in fp32 and are rounded to
+ * fp16 once.
+ *
+ * Return value: 0 on success, a negative W4A16_E* code otherwise.  Nothing is
+ * enqueued when a code is returned for an argument error.
+ */
+#ifndef W4A16_H_
+#define W4A16_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W4A16_ABI_VERSION 1
+
+enum {
+  W4A16_OK = 0,
+  W4A16_E_OC_PACK = -1,   /* "OC is not multiple of pack_num = 8"   (gemm_kernels.cu:414-415) */
+  W4A16_E_GROUP32 = -2,   /* "Group size should be a multiple of 32" (gemm_kernels.cu:416-417) */
+  W4A16_E_K_GROUP = -3,   /* K is not a multiple of the group size   (awq.py:84-88)            */
+  W4A16_E_NULL = -4,      /* a required pointer is NULL                                         */
+  W4A16_E_SHAPE = -5,     /* M, K, N or G is not positive, or K is not a multiple of 32         */
+  W4A16_E_ALIGN = -6,     /* a pointer is not 16-byte aligned                                   */
+  W4A16_E_LAUNCH = -7,    /* the HIP runtime refused the launch; see w4a16_last_hip_error()     */
+  W4A16_E_TOO_LARGE = -8  /* an index would overflow 32 bits                                    */
+};
+
+/* Human-readable text for a return code (host pointer, static storage). */
+const char* w4a16_strerror(int code);
+
+/* hipError_t of the last failed launch on this host thread (0 if none). */
+int w4a16_last_hip_error(void);
+
+/* Returns W4A16_ABI_VERSION of the loaded library. */
+int w4a16_abi_version(void);
+
+/*
+ * out = x @ dequant(qweight, qzeros, scales), on the stock AWQ tensors.
+ * Replaces:  torch::Tensor awq_gemm(_in_feats, _kernel, _scaling_factors, _zeros, split_k_iters)
+ *            csrc/quantization/awq/gemm_kernels.cu:389-446 (declared csrc/ops.h:69-74,
+ *            bound csrc/pybind.cpp:52-55).
+ * `split_k_iters` is accepted for signature parity and ignored (the reference
+ * uses it only to size its [split_k, M, N] scratch tensor and the trailing sum).
+ * Unlike the reference this accepts any N % 8 == 0 (the reference needs N % 64 == 0,
+ * which excludes 1376-wide tensor-parallel shards).
+ * This entry point reads the stock layout directly and is the shape-agnostic
+ * path; the tuned path is w4a16_repack() once + w4a16_gemm_packed_f16().
+ */
+int w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                   void* out, int M, int K, int N, int G, int split_k_iters, void* stream);
+
+/*
+ * out[K, N] fp16 = dequant(qweight, qzeros, scales).
+ * Replaces:  torch::Tensor awq_dequantize(_kernel, _scaling_factors, _zeros, split_k_iters, thx, thy)
+ *            csrc/quantization/awq/gemm_kernels.cu:332-381 (declared csrc/ops.h:76-82).
+ * The reference's split_k_iters/thx/thy are launch hints with no effect on the
+ * result and have no counterpart here.
+ */
+int w4a16_dequantize_f16(const void* qweight, const void* scales, const void* qzeros, void* out,
+                         int K, int N, int G, void* stream);
+
+/*
+ * Sizes in bytes of the private MFMA-ordered buffers w4a16_repack() fills.
+ * Pure host arithmetic.  Both return 0 for invalid shapes.
+ * No counterpart in the reference: its kernel consumes the stock layout and
+ * pays for that with a shared-memory round trip of the dequantised weights
+ * (gemm_kernels.cu:139-169).
+ */
+size_t w4a16_packed_weight_bytes(int K, int N);
+size_t w4a16_packed_sz_bytes(int K, int N, int G);
+
+/*
+ * One-time re-layout of the stock tensors into the private format
+ *   packed_w  : [ceil(N/16)][ceil(K/128)][64 lanes][4] uint32 - word j of lane l of block
+ *               (nt, kb) holds k = 128 kb + 32 j + 8 (l >> 4) + i (i = 0..7, nibble order
+ *               {0,4,1,5,2,6,3,7}) of column n = 16 nt + (l & 15): one 16-byte load per lane
+ *               is four ready-made 16x16x32 MFMA A-operand fragments.
+ *   packed_sz : [ceil(N/16)][K/G][16] uint32 - low half fp16 scale, high half fp16 -(1024 + zero).
+ * Padding (n >= N, k >= K) is zero-filled.  The stock tensors are not modified.
+ */
+int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, void* packed_w,
+                 void* packed_sz, int K, int N, int G, void* stream);
+
+/*
+ * out = x @ W (+ bias) from the private format.  `bias` ([N] fp16) may be NULL.
+ * This is the kernel behind awq_gemm / AWQLinearMethod.apply_weights
+ * (vllm/model_executor/layers/quantization/awq.py:143-165) once a layer's
+ * weights have been repacked; the optional bias folds awq.py:163-164 into the
+ * epilogue.
+ */
+int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
+                          const void* bias, void* out, int M, int K, int N, int G, void* stream);
+
+/*
+ * Same as w4a16_gemm_packed_f16 with an explicit launch shape, for tuning and
+ * tests: mt = 16-row output tiles per workgroup (1, 2, 4 or 8), t = 16-column
+ * tiles per workgroup (1..8, mt * t <= 24), waves = wavefronts per workgroup
+ * (1, 2, 4, 8 or 16).  Invalid combinations return W4A16_E_SHAPE.
+ */
+int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                              const void* bias, void* out, int M, int K, int N, int G, int mt,
+                              int t, int waves, void* stream);
+
+/*
+ * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16
+ * on the tensors the buffers were packed from).
+ */
+int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,
+                                int N, int G, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W4A16_H_ */

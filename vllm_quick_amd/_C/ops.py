@@ -1,0 +1,269 @@
+"""`ops` submodule with the reference's AWQ operator signatures.
+
+Mirrors `vllm._C.ops.awq_gemm` / `awq_dequantize` (csrc/pybind.cpp:52-55,
+csrc/ops.h:69-82 of the reference): same positional arguments, same result
+shape/dtype/device, same exception types (ValueError for shape violations, as
+pybind maps std::invalid_argument; RuntimeError for dtype/device mismatches, as
+`data_ptr<at::Half>()` raises).  Everything is computed by libw4a16.so on the
+GPU; CPU tensors are rejected.
+
+The functions are asynchronous (they enqueue on torch's current stream and
+return) and allocate only the result tensor, through torch's caching allocator,
+so they can be captured in a HIP graph once a layer's weights have been
+repacked by an earlier (warm-up) call.
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .._lib import check, lib
+
+PACK_FACTOR = 8
+
+
+# --------------------------------------------------------------------------
+# argument checks
+# --------------------------------------------------------------------------
+def _require(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        want = {torch.float16: "Half", torch.int32: "Int"}[dtype]
+        raise RuntimeError(f"expected scalar type {want} but found {t.dtype} for {name}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: the W4A16 path has no CPU implementation")
+
+
+def _geometry(kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch.Tensor) -> Tuple[int, int, int]:
+    _require(kernel, torch.int32, "kernel")
+    _require(scaling_factors, torch.float16, "scaling_factors")
+    _require(zeros, torch.int32, "zeros")
+    if kernel.dim() != 2 or scaling_factors.dim() != 2 or zeros.dim() != 2:
+        raise ValueError("kernel, scaling_factors and zeros must be 2-D")
+    K, NC = kernel.shape
+    N = NC * PACK_FACTOR
+    groups = scaling_factors.shape[0]
+    if groups == 0 or K % groups != 0:
+        raise ValueError("IC is not multiple of Group size")
+    G = K // groups
+    if scaling_factors.shape[1] != N:
+        raise ValueError(f"scaling_factors must be [{groups}, {N}], got {tuple(scaling_factors.shape)}")
+    if tuple(zeros.shape) != (groups, NC):
+        raise ValueError(f"zeros must be [{groups}, {NC}], got {tuple(zeros.shape)}")
+    if not (kernel.device == scaling_factors.device == zeros.device):
+        raise RuntimeError("kernel, scaling_factors and zeros must be on the same device")
+    return K, N, G
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _on_device:
+    """Makes `device` current for the duration of a call (OptionalCUDAGuard, gemm_kernels.cu:398)."""
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+# --------------------------------------------------------------------------
+# private (MFMA-ordered) weights
+# --------------------------------------------------------------------------
+@dataclass
+class PackedAWQ:
+    """A layer's weights in libw4a16's private layout (see include/w4a16.h, w4a16_repack)."""
+    packed_w: torch.Tensor  # uint8 [w4a16_packed_weight_bytes]
+    packed_sz: torch.Tensor  # uint8 [w4a16_packed_sz_bytes]
+    K: int
+    N: int
+    G: int
+
+    @property
+    def device(self) -> torch.device:
+        return self.packed_w.device
+
+
+def awq_repack(kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch.Tensor) -> PackedAWQ:
+    """Stock AWQ tensors -> PackedAWQ (one-time, on the GPU; inputs are left untouched)."""
+    K, N, G = _geometry(kernel, scaling_factors, zeros)
+    kernel, scaling_factors, zeros = kernel.contiguous(), scaling_factors.contiguous(), zeros.contiguous()
+    wbytes = lib.w4a16_packed_weight_bytes(K, N)
+    sbytes = lib.w4a16_packed_sz_bytes(K, N, G)
+    if wbytes == 0 or sbytes == 0:
+        raise ValueError(f"cannot repack K={K} N={N} G={G}")
+    with _on_device(kernel.device):
+        pw = torch.empty(wbytes, dtype=torch.uint8, device=kernel.device)
+        ps = torch.empty(sbytes, dtype=torch.uint8, device=kernel.device)
+        check(
+            lib.w4a16_repack(kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), pw.data_ptr(),
+                             ps.data_ptr(), K, N, G, _stream()), "awq_repack")
+    return PackedAWQ(pw, ps, K, N, G)
+
+
+def awq_gemm_packed(in_feats: torch.Tensor,
+                    packed: PackedAWQ,
+                    bias: Optional[torch.Tensor] = None,
+                    cfg: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves) overrides the launch shape."""
+    _require(in_feats, torch.float16, "in_feats")
+    if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
+        raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
+    if in_feats.device != packed.device:
+        raise RuntimeError("in_feats and the packed weights are on different devices")
+    x = in_feats.contiguous()  # the reference reads raw data_ptr and assumes this (gemm_kernels.cu:405)
+    M = x.shape[0]
+    bias_ptr = None
+    if bias is not None:
+        _require(bias, torch.float16, "bias")
+        if bias.numel() != packed.N:
+            raise ValueError(f"bias must have {packed.N} elements")
+        bias = bias.contiguous()
+        bias_ptr = bias.data_ptr()
+    with _on_device(x.device):
+        out = torch.empty((M, packed.N), dtype=torch.float16, device=x.device)
+        if M == 0:
+            return out
+        if cfg is None:
+            rc = lib.w4a16_gemm_packed_f16(x.data_ptr(), packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
+                                           bias_ptr, out.data_ptr(), M, packed.K, packed.N, packed.G, _stream())
+        else:
+            mt, t, waves = cfg
+            rc = lib.w4a16_gemm_packed_f16_cfg(x.data_ptr(), packed.packed_w.data_ptr(),
+                                               packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M, packed.K,
+                                               packed.N, packed.G, mt, t, waves, _stream())
+        check(rc, "awq_gemm")
+    return out
+
+
+def awq_gemm_stock(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors: torch.Tensor,
+                   zeros: torch.Tensor) -> torch.Tensor:
+    """Shape-agnostic GEMM straight from the stock tensors (no repack, nothing cached)."""
+    K, N, G = _geometry(kernel, scaling_factors, zeros)
+    _require(in_feats, torch.float16, "in_feats")
+    if in_feats.dim() != 2 or in_feats.shape[1] != K:
+        raise ValueError(f"in_feats must be [M, {K}], got {tuple(in_feats.shape)}")
+    x = in_feats.contiguous()
+    kernel, scaling_factors, zeros = kernel.contiguous(), scaling_factors.contiguous(), zeros.contiguous()
+    M = x.shape[0]
+    with _on_device(x.device):
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+        if M:
+            check(
+                lib.w4a16_gemm_f16(x.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
+                                   out.data_ptr(), M, K, N, G, PACK_FACTOR, _stream()), "awq_gemm")
+    return out
+
+
+# Repack cache for callers that hand over stock tensors on every call (the
+# reference signature).  An entry is reused only for the very same tensor
+# objects at the same version counters, so in-place weight loading, freed and
+# re-used addresses and fresh views all miss and re-pack.
+class _CacheEntry:
+    __slots__ = ("refs", "versions", "packed")
+
+    def __init__(self, tensors, packed):
+        self.refs = tuple(weakref.ref(t) for t in tensors)
+        self.versions = tuple(t._version for t in tensors)
+        self.packed = packed
+
+    def matches(self, tensors) -> bool:
+        return all(r() is t for r, t in zip(self.refs, tensors)) and \
+            self.versions == tuple(t._version for t in tensors)
+
+
+_repack_cache: Dict[Tuple, _CacheEntry] = {}
+_CACHE_LIMIT = 4096
+
+
+def _cached_pack(kernel, scaling_factors, zeros) -> Optional[PackedAWQ]:
+    key = (kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), tuple(kernel.shape),
+           scaling_factors.shape[0], kernel.device.index)
+    tensors = (kernel, scaling_factors, zeros)
+    entry = _repack_cache.get(key)
+    if entry is not None and entry.matches(tensors):
+        return entry.packed
+    if torch.cuda.is_current_stream_capturing():
+        return None  # never re-layout or allocate persistent state inside a graph capture
+    if len(_repack_cache) >= _CACHE_LIMIT:
+        dead = [k for k, e in _repack_cache.items() if any(r() is None for r in e.refs)]
+        for k in dead:
+            del _repack_cache[k]
+        if len(_repack_cache) >= _CACHE_LIMIT:
+            _repack_cache.clear()
+    packed = awq_repack(kernel, scaling_factors, zeros)
+    _repack_cache[key] = _CacheEntry(tensors, packed)
+    return packed
+
+
+def clear_repack_cache() -> None:
+    _repack_cache.clear()
+
+
+# --------------------------------------------------------------------------
+# the reference's two operators
+# --------------------------------------------------------------------------
+def awq_gemm(_in_feats: torch.Tensor, _kernel: torch.Tensor, _scaling_factors: torch.Tensor, _zeros: torch.Tensor,
+             split_k_iters: int) -> torch.Tensor:
+    """Reference: csrc/quantization/awq/gemm_kernels.cu:389-446.
+
+    [M, IC] fp16, [IC, OC/8] int32, [IC/G, OC] fp16, [IC/G, OC/8] int32 -> new [M, OC] fp16.
+    `split_k_iters` is accepted and ignored.  OC % 64 is not required (the
+    reference needs it, gemm_kernels.cu:412-413; 1376-wide TP shards do not
+    satisfy it); OC % 8, G % 32 and IC % G are.
+    """
+    K, N, G = _geometry(_kernel, _scaling_factors, _zeros)
+    _require(_in_feats, torch.float16, "in_feats")
+    if _in_feats.dim() != 2 or _in_feats.shape[1] != K:
+        raise ValueError(f"in_feats must be [M, {K}], got {tuple(_in_feats.shape)}")
+    if G % 32 != 0:
+        raise ValueError("Group size should be a multiple of 32")
+    packed = None
+    if _kernel.is_contiguous() and _scaling_factors.is_contiguous() and _zeros.is_contiguous():
+        packed = _cached_pack(_kernel, _scaling_factors, _zeros)
+    if packed is None:
+        return awq_gemm_stock(_in_feats, _kernel, _scaling_factors, _zeros)
+    return awq_gemm_packed(_in_feats, packed)
+
+
+def awq_dequantize(_kernel: torch.Tensor, _scaling_factors: torch.Tensor, _zeros: torch.Tensor, split_k_iters: int,
+                   thx: int, thy: int) -> torch.Tensor:
+    """Reference: csrc/quantization/awq/gemm_kernels.cu:332-381.
+
+    -> new [IC, OC] tensor with the dtype/device of `_scaling_factors`.
+    `split_k_iters`, `thx`, `thy` only shaped the reference's launch; ignored.
+    """
+    K, N, G = _geometry(_kernel, _scaling_factors, _zeros)
+    if G % 32 != 0:
+        raise ValueError("Group size should be a multiple of 32")
+    kernel, scaling_factors, zeros = _kernel.contiguous(), _scaling_factors.contiguous(), _zeros.contiguous()
+    with _on_device(kernel.device):
+        out = torch.empty((K, N), dtype=torch.float16, device=kernel.device)
+        check(
+            lib.w4a16_dequantize_f16(kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), out.data_ptr(),
+                                     K, N, G, _stream()), "awq_dequantize")
+    return out
+
+
+def awq_dequantize_packed(packed: PackedAWQ) -> torch.Tensor:
+    """[IC, OC] fp16 from the private layout (bit-identical to awq_dequantize on the source tensors)."""
+    with _on_device(packed.device):
+        out = torch.empty((packed.K, packed.N), dtype=torch.float16, device=packed.device)
+        check(
+            lib.w4a16_dequantize_packed_f16(packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(), out.data_ptr(),
+                                            packed.K, packed.N, packed.G, _stream()), "awq_dequantize_packed")
+    return out

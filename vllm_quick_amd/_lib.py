@@ -1,0 +1,67 @@
+"""ctypes binding of libw4a16.so (the C ABI declared in include/w4a16.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There
+is no fallback of any kind: if the shared object is missing or lacks a symbol,
+importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libw4a16.so")
+
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); must list every symbol include/w4a16.h declares.
+SYMBOLS = {
+    "w4a16_strerror": (c_char_p, [c_int]),
+    "w4a16_last_hip_error": (c_int, []),
+    "w4a16_abi_version": (c_int, []),
+    "w4a16_gemm_f16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "w4a16_dequantize_f16": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "w4a16_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "w4a16_packed_sz_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "w4a16_repack": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "w4a16_gemm_packed_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "w4a16_gemm_packed_f16_cfg": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+}
+
+# Return codes that mirror the reference's std::invalid_argument (-> ValueError).
+_VALUE_ERRORS = {-1, -2, -3, -5}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no non-HIP fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover - build mismatch
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.w4a16_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI {lib.w4a16_abi_version()} != expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str) -> None:
+    """Raise the Python exception that corresponds to a C return code."""
+    if code == 0:
+        return
+    msg = lib.w4a16_strerror(code).decode()
+    if code in _VALUE_ERRORS:
+        raise ValueError(f"{what}: {msg}")
+    if code == -7:
+        raise RuntimeError(f"{what}: {msg} (hipError {lib.w4a16_last_hip_error()})")
+    raise RuntimeError(f"{what}: {msg}")

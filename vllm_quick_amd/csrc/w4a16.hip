@@ -1,0 +1,714 @@
+// AWQ W4A16 GEMM for gfx950 (MI355X): kernels and the C ABI of libw4a16.so.
+//
+// Design
+// ------
+// The stock AWQ tensor packs eight adjacent OUTPUT columns of one k into a
+// dword.  A gfx950 fp16 MFMA operand wants eight adjacent k of one column per
+// lane.  w4a16_repack() therefore re-orders the weights once into 1-KiB blocks
+// of 16 columns x 128 k in which lane l's 16 bytes are, after the usual
+// magic-number int4->fp16 conversion, four ready-made A-operand fragments of
+// v_mfma_f32_16x16x32_f16 (weights are the A operand: the 16 rows of the tile
+// are output channels, so no matrix-core row is wasted on padding when M is
+// small, and each lane ends up holding 4 adjacent output columns of one
+// token, which store as 8 contiguous bytes).
+//
+// One kernel template serves decode and prefill.  A workgroup owns T column
+// tiles x MT row tiles of the output over the WHOLE of K; its W wavefronts
+// split K between them (wave w takes 128-k blocks w, w+W, ...), stream their
+// weight blocks HBM -> VGPR with 16-byte loads, dequantise in registers
+// (bit-exactly the reference's fp16((q - z) * s)), feed the matrix cores, and
+// combine their fp32 partial tiles through LDS at the end.  There is no
+// cross-workgroup split-K, hence no workspace, no atomics and a result that
+// does not depend on dispatch order.
+//
+// Reference behaviour replaced: csrc/quantization/awq/gemm_kernels.cu:30-272
+// (GEMM), :274-381 (dequantize), csrc/quantization/awq/dequantize.cuh:17-84.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/w4a16.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Logical element i of a packed word sits in nibble kOrder[i].
+__device__ __constant__ const int kOrderDev[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+
+__device__ __forceinline__ f16x2 as_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+constexpr uint32_t kMagic = 0x64006400u;  // half2 {1024, 1024}
+constexpr uint32_t kLoMask = 0x000f000fu;
+constexpr uint32_t kHiMask = 0x00f000f0u;
+
+// Per-(group, column) constants of the private format, expanded for packed math.
+struct SZ {
+  f16x2 s;    // {scale, scale}
+  f16x2 nz1;  // {-(1024 + z)} x2 : turns (1024 + q) into q - z
+  f16x2 nz2;  // {-(64 + z)} x2   : turns (1024 + 16 q) / 16 into q - z
+};
+
+__device__ __forceinline__ SZ expand_sz(uint32_t w) {
+  const f16x2 v = as_h2(w);
+  SZ r;
+  r.s = f16x2{v.x, v.x};
+  r.nz1 = f16x2{v.y, v.y};
+  r.nz2 = r.nz1 + f16x2{(f16)960.0f, (f16)960.0f};
+  return r;
+}
+
+// One packed word (8 k of one column) -> 8 fp16 weights in k order.
+// q - z is formed exactly, then rounded once in the multiply by the scale:
+// the same value as sub.f16x2 + fma.rn.f16x2 in gemm_kernels.cu:153-160.
+__device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c) {
+  const uint32_t t = w >> 8;
+  const f16x2 h0 = as_h2((w & kLoMask) | kMagic);
+  const f16x2 h1 = as_h2((w & kHiMask) | kMagic);
+  const f16x2 h2 = as_h2((t & kLoMask) | kMagic);
+  const f16x2 h3 = as_h2((t & kHiMask) | kMagic);
+  const f16x2 sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
+  const f16x2 d0 = (h0 + c.nz1) * c.s;
+  const f16x2 d1 = (h1 * sixteenth + c.nz2) * c.s;
+  const f16x2 d2 = (h2 + c.nz1) * c.s;
+  const f16x2 d3 = (h3 * sixteenth + c.nz2) * c.s;
+  return f16x8{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
+}
+
+// ---------------------------------------------------------------------------
+// GEMM on the private layout
+// ---------------------------------------------------------------------------
+// Waves whose partial tiles (1 KiB per 16x16 tile) take part in the final LDS round.
+constexpr int kLdsTiles = 64;
+constexpr int live_waves(int W, int TM) {
+  int live = W;
+  while (live > 1 && live * TM > kLdsTiles) live /= 2;
+  return live;
+}
+// Tiles of LDS the reduction needs: the first fold holds W/2 sets, the final round LIVE sets.
+constexpr int reduce_lds_tiles(int W, int TM) {
+  if (W == 1) return 0;
+  const int live = live_waves(W, TM);
+  return (live < W ? W / 2 : live) * TM;
+}
+
+struct GemmArgs {
+  const f16* x;
+  const u32x4* pw;      // [NT][KB][64] x 16 bytes
+  const uint32_t* psz;  // [NT][NG][16]
+  const f16* bias;      // may be null
+  f16* out;
+  int M, K, N, G;
+  int NT, KB, NG;
+};
+
+// MT : 16-row tiles of the output per workgroup
+// T  : 16-column tiles per workgroup
+// W  : wavefronts per workgroup (they split K)
+// SZS: k-steps (of 32) covered by one scale/zero word: 4 when G % 128 == 0,
+//      2 when G == 64, 1 for any other multiple of 32
+template <int MT, int T, int W, int SZS>
+__global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
+  constexpr int NSZ = 4 / SZS;  // scale/zero words per 128-k block and tile
+  constexpr int TM = T * MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15;
+  const int kq = lane >> 4;
+  const int nt0 = blockIdx.x * T;
+  const int m0 = blockIdx.y * (MT * 16);
+
+  const u32x4* wp[T];
+  const uint32_t* szp[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    // Tiles past the end re-read the last tile (valid memory); their results are dropped.
+    const int nt = min(nt0 + t, a.NT - 1);
+    wp[t] = a.pw + (size_t)nt * a.KB * 64 + lane;
+    szp[t] = a.psz + (size_t)nt * a.NG * 16 + n16;
+  }
+  // Rows past M re-read row M-1: output row m depends on x row m only, and rows >= M
+  // are never stored, so no masking is needed.
+  const f16* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(m0 + mt * 16 + n16, a.M - 1);
+    xp[mt] = a.x + (size_t)row * a.K + kq * 8;
+  }
+
+  f32x4 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Block {
+    u32x4 q[T];
+    uint32_t sz[T][NSZ];
+  };
+
+  auto load_block = [&](int kb, Block& b) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) b.q[t] = __builtin_nontemporal_load(wp[t] + (size_t)kb * 64);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        b.sz[t][s] = szp[t][g * 16];
+      }
+  };
+
+  // k-steps past K (K not a multiple of 128, or the prefetch after the last block)
+  // re-read k = 0: the packer fills k >= K with q = z, i.e. exact zero weights.
+  auto load_x = [&](int k, f16x8 (&xf)[MT]) {
+    const int ke = (k < a.K) ? k : 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f16x8*>(xp[mt] + ke);
+  };
+
+  // One 128-k block: 4 k-steps of (T dequantised A fragments) x (MT x fragments).
+  // `xf` holds the x fragments of this block's first k-step on entry and those of
+  // block `kb_next`'s first k-step on exit (loaded one k-step ahead throughout).
+  auto compute_block = [&](int kb, int kb_next, const Block& b, f16x8 (&xf)[MT]) {
+    SZ c[T];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 xn[MT];
+      const int knext = (j < 3) ? kb * 128 + (j + 1) * 32 : kb_next * 128;
+      load_x(knext, xn);
+      if (j % SZS == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) c[t] = expand_sz(b.sz[t][j / SZS]);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const f16x8 af = dequant_word(b.q[t][j], c[t]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = xn[mt];
+    }
+  };
+
+  // K loop, weights double-buffered one block ahead.  Blocks past KB are never
+  // computed; `kb_next * 128 >= K` makes their x prefetch a zero fill.
+  {
+    Block b0, b1;
+    f16x8 xf[MT];
+    int kb = w;
+    if (kb < a.KB) {
+      load_block(kb, b0);
+      load_x(kb * 128, xf);
+    }
+    while (kb < a.KB) {
+      int kn = kb + W;
+      if (kn < a.KB) load_block(kn, b1);
+      compute_block(kb, kn, b0, xf);
+      kb = kn;
+      if (kb >= a.KB) break;
+      kn = kb + W;
+      if (kn < a.KB) load_block(kn, b0);
+      compute_block(kb, kn, b1, xf);
+      kb = kn;
+    }
+  }
+
+  // Cross-wave reduction through LDS: fold the upper half of the live waves onto the
+  // lower half until LIVE partial sets fit the budget, then every wave sums whole tiles.
+  constexpr int LIVE = live_waves(W, TM);
+  auto store_tile = [&](int i, f32x4 v) {
+    // C layout of the MFMA: register r of lane l is row 4 (l >> 4) + r of the tile
+    // (a column n of `out`), column l & 15 (a row m of `out`).
+    const int t = i / MT, mt = i - t * MT;
+    const int nt = nt0 + t;
+    const int n = nt * 16 + kq * 4;
+    const int m = m0 + mt * 16 + n16;
+    if (nt < a.NT && n < a.N && m < a.M) {
+      // Round to fp16 first, then add the bias in fp16: the value of `out + bias`
+      // on an fp16 GEMM result (awq.py:163-164).
+      f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
+      *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
+    }
+  };
+  if constexpr (W == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) store_tile(i, acc[i / MT][i % MT]);
+  } else {
+#pragma unroll
+    for (int cur = W; cur > LIVE; cur >>= 1) {
+      const int half = cur >> 1;
+      if (w >= half && w < cur) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) red[((w - half) * TM + i) * 64 + lane] = acc[i / MT][i % MT];
+      }
+      __syncthreads();
+      if (w < half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i / MT][i % MT] += red[(w * TM + i) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (w < LIVE) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) red[(w * TM + i) * 64 + lane] = acc[i / MT][i % MT];
+    }
+    __syncthreads();
+    for (int i = w; i < TM; i += W) {
+      f32x4 v = red[i * 64 + lane];
+#pragma unroll
+      for (int s = 1; s < LIVE; ++s) v += red[(s * TM + i) * 64 + lane];
+      store_tile(i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Shape-agnostic GEMM on the stock layout (no repack, no workspace)
+// ---------------------------------------------------------------------------
+// One thread owns one packed column word (8 output columns) for up to RB rows.
+template <int RB>
+__global__ void __launch_bounds__(64) gemm_stock_kernel(const f16* __restrict__ x,
+                                                        const uint32_t* __restrict__ qw,
+                                                        const f16* __restrict__ scales,
+                                                        const uint32_t* __restrict__ qz,
+                                                        f16* __restrict__ out, int M, int K,
+                                                        int N, int G) {
+  const int NC = N / 8;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int m0 = blockIdx.y * RB;
+  if (c >= NC) return;
+  float acc[RB][8];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+
+  const f16x2 sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
+  for (int g = 0; g < K / G; ++g) {
+    const uint32_t zw = qz[(size_t)g * NC + c];
+    const u32x4 sw = *reinterpret_cast<const u32x4*>(scales + (size_t)g * N + 8 * c);
+    const uint32_t zt = zw >> 8;
+    const f16x2 z0 = as_h2((zw & kLoMask) | kMagic), z1 = as_h2((zw & kHiMask) | kMagic);
+    const f16x2 z2 = as_h2((zt & kLoMask) | kMagic), z3 = as_h2((zt & kHiMask) | kMagic);
+    const f16x2 s0 = as_h2(sw.x), s1 = as_h2(sw.y), s2 = as_h2(sw.z), s3 = as_h2(sw.w);
+    for (int k = g * G; k < (g + 1) * G; ++k) {
+      const uint32_t q = qw[(size_t)k * NC + c];
+      const uint32_t t = q >> 8;
+      const f16x2 d0 = (as_h2((q & kLoMask) | kMagic) - z0) * s0;
+      const f16x2 d1 = ((as_h2((q & kHiMask) | kMagic) - z1) * sixteenth) * s1;
+      const f16x2 d2 = (as_h2((t & kLoMask) | kMagic) - z2) * s2;
+      const f16x2 d3 = ((as_h2((t & kHiMask) | kMagic) - z3) * sixteenth) * s3;
+      const float wv[8] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y,
+                           (float)d2.x, (float)d2.y, (float)d3.x, (float)d3.y};
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int m = m0 + r;
+        const float xv = (m < M) ? (float)x[(size_t)m * K + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(xv, wv[j], acc[r][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int m = m0 + r;
+    if (m < M) {
+      f16x8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (f16)acc[r][j];
+      *reinterpret_cast<f16x8*>(out + (size_t)m * N + 8 * c) = h;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Dequantize (stock layout) : one thread per packed word -> 16-byte store
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dequant_stock_kernel(const uint32_t* __restrict__ qw,
+                                                            const f16* __restrict__ scales,
+                                                            const uint32_t* __restrict__ qz,
+                                                            f16* __restrict__ out, int K, int N,
+                                                            int G) {
+  const int NC = N / 8;
+  const size_t total = (size_t)K * NC;
+  const f16x2 sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * 256) {
+    const int k = (int)(idx / NC);
+    const int c = (int)(idx - (size_t)k * NC);
+    const int g = k / G;
+    const uint32_t q = qw[idx];
+    const uint32_t zw = qz[(size_t)g * NC + c];
+    const u32x4 sw = *reinterpret_cast<const u32x4*>(scales + (size_t)g * N + 8 * c);
+    const uint32_t t = q >> 8, zt = zw >> 8;
+    const f16x2 d0 = (as_h2((q & kLoMask) | kMagic) - as_h2((zw & kLoMask) | kMagic)) * as_h2(sw.x);
+    const f16x2 d1 = ((as_h2((q & kHiMask) | kMagic) - as_h2((zw & kHiMask) | kMagic)) * sixteenth) *
+                     as_h2(sw.y);
+    const f16x2 d2 = (as_h2((t & kLoMask) | kMagic) - as_h2((zt & kLoMask) | kMagic)) * as_h2(sw.z);
+    const f16x2 d3 = ((as_h2((t & kHiMask) | kMagic) - as_h2((zt & kHiMask) | kMagic)) * sixteenth) *
+                     as_h2(sw.w);
+    const u32x4 o = u32x4{as_u32(d0), as_u32(d1), as_u32(d2), as_u32(d3)};
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + (size_t)k * N + 8 * c));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Re-layout: stock -> private
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) repack_weight_kernel(const uint32_t* __restrict__ qw,
+                                                            const uint32_t* __restrict__ qz,
+                                                            uint32_t* __restrict__ pw, int K, int N,
+                                                            int G, int NT, int KB) {
+  const int NC = N / 8;
+  const size_t total = (size_t)NT * KB * 256;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * 256) {
+    const int j = (int)(o & 3);
+    const int l = (int)((o >> 2) & 63);
+    const size_t blk = o >> 8;
+    const int kb = (int)(blk % KB);
+    const int nt = (int)(blk / KB);
+    const int n = nt * 16 + (l & 15);
+    const int k0 = kb * 128 + j * 32 + (l >> 4) * 8;
+    uint32_t word = 0;
+    if (n < N) {
+      const int src_shift = 4 * kOrderDev[n & 7];
+      // k >= K (K not a multiple of 128) is filled with the last group's zero point, so
+      // those weights dequantise to exactly 0 whatever activation they meet.
+      const uint32_t zpad = (qz[(size_t)(K / G - 1) * NC + (n >> 3)] >> src_shift) & 0xfu;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i;
+        const uint32_t v =
+            (k < K) ? ((qw[(size_t)k * NC + (n >> 3)] >> src_shift) & 0xfu) : zpad;
+        word |= v << (4 * kOrderDev[i]);
+      }
+    }
+    pw[o] = word;
+  }
+}
+
+__global__ void __launch_bounds__(256) repack_sz_kernel(const f16* __restrict__ scales,
+                                                        const uint32_t* __restrict__ qz,
+                                                        uint32_t* __restrict__ psz, int N, int NT,
+                                                        int NG) {
+  const int NC = N / 8;
+  const size_t total = (size_t)NT * NG * 16;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * 256) {
+    const int n16 = (int)(o & 15);
+    const size_t r = o >> 4;
+    const int g = (int)(r % NG);
+    const int nt = (int)(r / NG);
+    const int n = nt * 16 + n16;
+    uint32_t word = 0;
+    if (n < N) {
+      const uint32_t z = (qz[(size_t)g * NC + (n >> 3)] >> (4 * kOrderDev[n & 7])) & 0xfu;
+      const uint32_t sbits = *reinterpret_cast<const uint16_t*>(scales + (size_t)g * N + n);
+      word = sbits | ((0xE400u | z) << 16);  // fp16 -(1024 + z)
+    }
+    psz[o] = word;
+  }
+}
+
+// Dequantize from the private layout (rarely needed: M >= 256 dense path after
+// the stock tensors were dropped).  One thread per packed word.
+__global__ void __launch_bounds__(256) dequant_packed_kernel(const uint32_t* __restrict__ pw,
+                                                             const uint32_t* __restrict__ psz,
+                                                             f16* __restrict__ out, int K, int N,
+                                                             int G, int NT, int KB, int NG) {
+  const size_t total = (size_t)NT * KB * 256;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * 256) {
+    const int j = (int)(o & 3);
+    const int l = (int)((o >> 2) & 63);
+    const size_t blk = o >> 8;
+    const int kb = (int)(blk % KB);
+    const int nt = (int)(blk / KB);
+    const int n = nt * 16 + (l & 15);
+    const int k0 = kb * 128 + j * 32 + (l >> 4) * 8;
+    if (n >= N || k0 >= K) continue;
+    const int g = k0 / G;
+    const SZ c = expand_sz(psz[((size_t)nt * NG + g) * 16 + (l & 15)]);
+    const f16x8 v = dequant_word(pw[o], c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (k0 + i < K) out[(size_t)(k0 + i) * N + n] = v[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+thread_local int g_last_hip_error = 0;
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+int check_common(int K, int N, int G) {
+  if (K <= 0 || N <= 0 || G <= 0) return W4A16_E_SHAPE;
+  if (N % 8) return W4A16_E_OC_PACK;
+  if (G % 32) return W4A16_E_GROUP32;
+  if (K % G) return W4A16_E_K_GROUP;
+  if ((long long)K * (N / 8) >= (1LL << 31)) return W4A16_E_TOO_LARGE;
+  return W4A16_OK;
+}
+
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+int launched() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return W4A16_E_LAUNCH;
+  }
+  return W4A16_OK;
+}
+
+template <int MT, int T, int W>
+int launch_packed(const GemmArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)reduce_lds_tiles(W, T * MT) * 1024;
+  const dim3 grid(ceil_div(a.NT, T), ceil_div(a.M, MT * 16));
+  const dim3 block(64 * W);
+  void (*kern)(const GemmArgs) = nullptr;
+  if (a.G % 128 == 0)
+    kern = gemm_packed_kernel<MT, T, W, 4>;
+  else if (a.G == 64)
+    kern = gemm_packed_kernel<MT, T, W, 2>;
+  else
+    kern = gemm_packed_kernel<MT, T, W, 1>;
+  if (lds > 64 * 1024) {
+    // Per device and per kernel; cheap next to a launch, and legal during stream capture.
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  return launched();
+}
+
+// (mt, t, waves) -> instantiation.  mt in {1,2,4,8}; t in 1..8 with mt*t <= 24;
+// waves 16 for mt <= 2 (128 VGPRs/lane are enough), 8 for mt >= 4; plus 4/8 for short K.
+#define W4A16_FOR_EACH_CFG(X) \
+  X(1, 1, 16) X(1, 2, 16) X(1, 3, 16) X(1, 4, 16) X(1, 6, 16)             \
+  X(1, 1, 8)  X(1, 2, 8)  X(1, 3, 8)  X(1, 4, 8)  X(1, 6, 8)  X(1, 8, 8)  \
+  X(1, 1, 4)  X(1, 2, 4)  X(1, 3, 4)  X(1, 4, 4)                          \
+  X(2, 1, 16) X(2, 2, 16) X(2, 3, 16) X(2, 4, 16)                         \
+  X(2, 1, 8)  X(2, 2, 8)  X(2, 3, 8)  X(2, 4, 8)  X(2, 6, 8)              \
+  X(2, 1, 4)  X(2, 2, 4)  X(2, 3, 4)                                      \
+  X(4, 1, 8)  X(4, 2, 8)  X(4, 3, 8)  X(4, 4, 8)  X(4, 6, 8)              \
+  X(4, 1, 4)  X(4, 2, 4)  X(4, 3, 4)                                      \
+  X(8, 1, 8)  X(8, 2, 8)  X(8, 3, 8)                                      \
+  X(8, 1, 4)  X(8, 2, 4)  X(8, 3, 4)
+
+int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s) {
+#define X(MT_, T_, W_) \
+  if (mt == MT_ && t == T_ && waves == W_) return launch_packed<MT_, T_, W_>(a, s);
+  W4A16_FOR_EACH_CFG(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
+int pow2_floor(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
+}
+
+// Default launch shape.  Workgroups own whole columns of the output (no
+// cross-workgroup reduction), so the aim is one workgroup per CU with every
+// CU busy: T = column tiles needed to cover N with ~256 workgroups.
+void choose_cfg(int M, int K, int N, int* mt, int* t, int* waves) {
+  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
+  const int mtiles = ceil_div(M, 16);
+  int MT = mtiles >= 8 ? 8 : mtiles > 2 ? 4 : mtiles;  // 1, 2, 4, 8
+  int Wv = (MT <= 2) ? 16 : 8;
+  while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
+  const int mblocks = ceil_div(mtiles, MT);
+  const int cus = 256;
+  // workgroups that fit a CU at once, by wave count (16 waves of <=128 VGPRs)
+  const int per_cu = 16 / Wv;
+  int Tt = ceil_div((long long)NT * mblocks, (long long)cus * per_cu);
+  if (Tt < 1) Tt = 1;
+  if (Tt == 5) Tt = 6;
+  if (Tt == 7) Tt = 8;
+  // largest T instantiated for this (MT, waves): see W4A16_FOR_EACH_CFG
+  int tmax;
+  if (MT == 1) tmax = (Wv == 16) ? 6 : (Wv == 8) ? 8 : 4;
+  else if (MT == 2) tmax = (Wv == 16) ? 4 : (Wv == 8) ? 6 : 3;
+  else if (MT == 4) tmax = (Wv == 8) ? 6 : 3;
+  else tmax = 3;
+  if (Tt > tmax) Tt = tmax;
+  *mt = MT;
+  *t = Tt;
+  *waves = Wv;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* w4a16_strerror(int code) {
+  switch (code) {
+    case W4A16_OK: return "ok";
+    case W4A16_E_OC_PACK: return "OC is not multiple of pack_num = 8";
+    case W4A16_E_GROUP32: return "Group size should be a multiple of 32";
+    case W4A16_E_K_GROUP: return "IC is not multiple of Group size";
+    case W4A16_E_NULL: return "null pointer argument";
+    case W4A16_E_SHAPE: return "invalid shape or launch configuration";
+    case W4A16_E_ALIGN: return "pointer is not 16-byte aligned";
+    case W4A16_E_LAUNCH: return "HIP launch failed";
+    case W4A16_E_TOO_LARGE: return "tensor too large for 32-bit indexing";
+    default: return "unknown w4a16 error";
+  }
+}
+
+int w4a16_last_hip_error(void) { return g_last_hip_error; }
+
+int w4a16_abi_version(void) { return W4A16_ABI_VERSION; }
+
+size_t w4a16_packed_weight_bytes(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  return (size_t)ceil_div(N, 16) * ceil_div(K, 128) * 1024;
+}
+
+size_t w4a16_packed_sz_bytes(int K, int N, int G) {
+  if (K <= 0 || N <= 0 || G <= 0 || K % G) return 0;
+  return (size_t)ceil_div(N, 16) * (K / G) * 16 * 4;
+}
+
+int w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                   void* out, int M, int K, int N, int G, int split_k_iters, void* stream) {
+  (void)split_k_iters;
+  if (!x || !qweight || !scales || !qzeros || !out) return W4A16_E_NULL;
+  if (M <= 0) return W4A16_E_SHAPE;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  if ((long long)M * N >= (1LL << 31) || (long long)M * K >= (1LL << 31)) return W4A16_E_TOO_LARGE;
+  if (misaligned(scales) || misaligned(out)) return W4A16_E_ALIGN;
+  const hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 block(64);
+  const int NC = N / 8;
+  if (M >= 4) {
+    const dim3 grid(ceil_div(NC, 64), ceil_div(M, 4));
+    hipLaunchKernelGGL(gemm_stock_kernel<4>, grid, block, 0, s, (const f16*)x,
+                       (const uint32_t*)qweight, (const f16*)scales, (const uint32_t*)qzeros,
+                       (f16*)out, M, K, N, G);
+  } else {
+    const dim3 grid(ceil_div(NC, 64), M);
+    hipLaunchKernelGGL(gemm_stock_kernel<1>, grid, block, 0, s, (const f16*)x,
+                       (const uint32_t*)qweight, (const f16*)scales, (const uint32_t*)qzeros,
+                       (f16*)out, M, K, N, G);
+  }
+  return launched();
+}
+
+int w4a16_dequantize_f16(const void* qweight, const void* scales, const void* qzeros, void* out,
+                         int K, int N, int G, void* stream) {
+  if (!qweight || !scales || !qzeros || !out) return W4A16_E_NULL;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  if (misaligned(scales) || misaligned(out)) return W4A16_E_ALIGN;
+  const size_t total = (size_t)K * (N / 8);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(dequant_stock_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const uint32_t*)qweight,
+                     (const f16*)scales, (const uint32_t*)qzeros, (f16*)out, K, N, G);
+  return launched();
+}
+
+int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, void* packed_w,
+                 void* packed_sz, int K, int N, int G, void* stream) {
+  if (!qweight || !scales || !qzeros || !packed_w || !packed_sz) return W4A16_E_NULL;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  if (K % 32) return W4A16_E_SHAPE;
+  if (misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
+  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
+  const hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    const size_t total = (size_t)NT * KB * 256;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(repack_weight_kernel, dim3(blocks), dim3(256), 0, s,
+                       (const uint32_t*)qweight, (const uint32_t*)qzeros, (uint32_t*)packed_w, K,
+                       N, G, NT, KB);
+    const int r = launched();
+    if (r) return r;
+  }
+  {
+    const size_t total = (size_t)NT * NG * 16;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(repack_sz_kernel, dim3(blocks), dim3(256), 0, s, (const f16*)scales,
+                       (const uint32_t*)qzeros, (uint32_t*)packed_sz, N, NT, NG);
+  }
+  return launched();
+}
+
+int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                              const void* bias, void* out, int M, int K, int N, int G, int mt,
+                              int t, int waves, void* stream) {
+  if (!x || !packed_w || !packed_sz || !out) return W4A16_E_NULL;
+  if (M <= 0) return W4A16_E_SHAPE;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  if (K % 32) return W4A16_E_SHAPE;
+  if ((long long)M * N >= (1LL << 31) || (long long)M * K >= (1LL << 31)) return W4A16_E_TOO_LARGE;
+  if (misaligned(x) || misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
+  if (reinterpret_cast<uintptr_t>(out) & 7u) return W4A16_E_ALIGN;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return W4A16_E_ALIGN;
+  GemmArgs a;
+  a.x = (const f16*)x;
+  a.pw = (const u32x4*)packed_w;
+  a.psz = (const uint32_t*)packed_sz;
+  a.bias = (const f16*)bias;
+  a.out = (f16*)out;
+  a.M = M;
+  a.K = K;
+  a.N = N;
+  a.G = G;
+  a.NT = ceil_div(N, 16);
+  a.KB = ceil_div(K, 128);
+  a.NG = K / G;
+  return dispatch_packed(a, mt, t, waves, static_cast<hipStream_t>(stream));
+}
+
+int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
+                          const void* bias, void* out, int M, int K, int N, int G, void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0) return W4A16_E_SHAPE;
+  int mt, t, waves;
+  choose_cfg(M, K, N, &mt, &t, &waves);
+  return w4a16_gemm_packed_f16_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, mt, t, waves,
+                                   stream);
+}
+
+int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,
+                                int N, int G, void* stream) {
+  if (!packed_w || !packed_sz || !out) return W4A16_E_NULL;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
+  const size_t total = (size_t)NT * KB * 256;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(dequant_packed_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const uint32_t*)packed_w,
+                     (const uint32_t*)packed_sz, (f16*)out, K, N, G, NT, KB, NG);
+  return launched();
+}
+
+}  // extern "C"
