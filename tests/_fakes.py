@@ -1,0 +1,30 @@
+"""Oracle-backed stand-ins for the native operators, for tests that run without a GPU.
+They live under tests/ because only tests may compute with the oracle."""
+import torch
+
+from oracle import awq_oracle as orc
+
+
+class FakeOps:
+
+    def __init__(self):
+        self.trace = []
+
+    def stream_is_capturing(self):
+        return False
+
+    def awq_repack(self, qweight, scales, qzeros):
+        self.trace.append(["repack"])
+        return (qweight, scales, qzeros)
+
+    def awq_gemm_packed(self, x, packed, bias=None, cfg=None):
+        self.trace.append(["awq_gemm", list(x.shape), bool(x.is_contiguous())])
+        qw, s, qz = packed
+        y = torch.from_numpy(
+            orc.gemm_faithful(x.numpy(), qw.detach().numpy(), s.detach().numpy(), qz.detach().numpy()))
+        return y if bias is None else y + bias
+
+    def awq_dequantize(self, qweight, scales, qzeros, split_k, thx, thy):
+        self.trace.append(["awq_dequantize", list(qweight.shape), split_k, thx, thy])
+        return torch.from_numpy(
+            orc.dequantize(qweight.detach().numpy(), scales.detach().numpy(), qzeros.detach().numpy()))

@@ -1,0 +1,105 @@
+"""Tensor-parallel column/row sharding of the W4A16 linear with world_size 2 on the gloo backend.
+
+Each rank builds the reference-style layers on top of AWQLinearMethod (native ops replaced by
+the oracle-backed fakes: there is no GPU here), loads its shard of one full checkpoint through
+the layers' weight loaders, and the results are compared with the unsharded oracle GEMM:
+column-parallel + all-gather must reproduce it, row-parallel partial products + all-reduce too.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        from _fakes import FakeOps
+        from oracle import awq_oracle as orc
+        from vllm_quick_amd.layers import linear as L
+        from vllm_quick_amd.layers.quantization import AWQConfig
+        from vllm_quick_amd.layers.quantization import awq as awq_mod
+        from vllm_quick_amd.parallel_utils import communication_op as comm
+        from vllm_quick_amd.parallel_utils import parallel_state as ps
+
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ps.initialize_model_parallel(world)
+        assert ps.get_tensor_model_parallel_world_size() == world
+        assert ps.get_tensor_model_parallel_rank() == rank
+        awq_mod.ops = FakeOps()
+        method = AWQConfig(4, 32, True).get_linear_method()
+
+        # collectives
+        t = torch.full((3, 4), float(rank + 1))
+        r = comm.tensor_model_parallel_all_reduce(t.clone())
+        assert torch.equal(r, torch.full((3, 4), float(sum(range(1, world + 1)))))
+        g = comm.tensor_model_parallel_all_gather(torch.full((2, 3), float(rank)), dim=-1)
+        assert g.shape == (2, 3 * world)
+        assert all(torch.equal(g[:, 3 * i:3 * i + 3], torch.full((2, 3), float(i))) for i in range(world))
+        g0 = comm.tensor_model_parallel_all_gather(torch.full((2, 3), float(rank)), dim=0)
+        assert g0.shape == (2 * world, 3) and torch.equal(g0[2 * rank], torch.full((3, ), float(rank)))
+
+        M, K, N = 5, 128, 192
+        x, qw, s, qz = orc.make_inputs(M, K, N, 32, seed=41)
+        want = orc.gemm_faithful(x, qw, s, qz).astype(np.float32)
+        ck = {"qweight": qw, "scales": s, "qzeros": qz}
+
+        col = L.ColumnParallelLinear(K, N, bias=False, gather_output=True, params_dtype=torch.float16,
+                                     linear_method=method)
+        for n, a in ck.items():
+            p = getattr(col, n)
+            p.weight_loader(p, torch.from_numpy(a))
+        assert col.qweight.shape == (K, N // 8 // world)
+        y, _ = col(torch.from_numpy(x))
+        assert y.shape == (M, N)
+        assert np.allclose(y.numpy().astype(np.float32), want, rtol=1e-2, atol=1e-3)
+
+        row = L.RowParallelLinear(K, N, bias=True, input_is_parallel=False, params_dtype=torch.float16,
+                                  linear_method=method)
+        for n, a in ck.items():
+            p = getattr(row, n)
+            p.weight_loader(p, torch.from_numpy(a))
+        assert row.qweight.shape == (K // world, N // 8) and row.scales.shape == (K // 32 // world, N)
+        bias = torch.linspace(-1, 1, N).half()
+        row.bias.data.copy_(bias)
+        y, ob = row(torch.from_numpy(x))
+        assert ob is None
+        assert np.allclose(y.detach().numpy().astype(np.float32), want + bias.float().numpy(), rtol=1e-2, atol=2e-3)
+
+        ps.destroy_model_parallel()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+def test_tp2_column_and_row_parallel_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in results:
+        assert status == "ok", f"rank {rank}:\n{status}"

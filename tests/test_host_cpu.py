@@ -1,0 +1,223 @@
+"""The host-side mirror (AWQConfig, AWQLinearMethod, linear layers) against behaviour captured
+from the REFERENCE's own Python (tests/golden/awq_reference_python.*, made by
+oracle/gen_golden.py, which imported /root/reference with the native ops faked by the oracle).
+
+No GPU: the native operators are replaced here by the same oracle-backed fakes, so what is
+compared is everything around the kernels - parameters, attributes, errors, dispatch, bias,
+reshape and tensor-parallel shard arithmetic.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as orc
+from _fakes import FakeOps
+from vllm_quick_amd.layers import linear as L
+from vllm_quick_amd.layers.quantization import AWQConfig, QuantizationConfig, get_quantization_config
+from vllm_quick_amd.layers.quantization import awq as awq_mod
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def meta():
+    return json.load(open(os.path.join(G, "awq_reference_python.json")))
+
+
+@pytest.fixture(scope="module")
+def arrays():
+    return np.load(os.path.join(G, "awq_reference_python.npz"))
+
+
+def caught(fn):
+    try:
+        fn()
+        return None
+    except Exception as e:  # noqa: BLE001
+        return [type(e).__name__, str(e)]
+
+
+def test_config_surface(meta):
+    want = meta["config"]
+    cfg = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    cfg2 = AWQConfig.from_config({"bits": 4, "group_size": 64, "zero_point": False})
+    assert repr(cfg) == want["repr"] and repr(cfg2) == want["repr2"]
+    assert cfg.get_name() == want["name"]
+    assert cfg.pack_factor == want["pack_factor"]
+    assert [str(d) for d in cfg.get_supported_act_dtypes()] == want["act_dtypes"]
+    assert cfg.get_min_capability() == want["min_capability"]
+    assert AWQConfig.get_config_filenames() == want["filenames"]
+    assert cfg.get_scaled_act_names() == want["scaled_act_names"]
+    assert (get_quantization_config("awq") is AWQConfig) == want["registry_awq_is_AWQConfig"]
+    assert isinstance(cfg, QuantizationConfig)
+    assert isinstance(cfg.get_linear_method(), L.LinearMethodBase)
+
+
+def test_config_errors(meta):
+    want = meta["config_errors"]
+    assert caught(lambda: AWQConfig(8, 128, True)) == want["bits8"]
+    assert caught(lambda: AWQConfig.from_config({"bits": 4, "zero_point": True})) == want["missing_key"]
+    assert caught(lambda: get_quantization_config("nope")) == want["bad_registry"]
+
+
+def test_create_weights(meta):
+    method = AWQConfig(4, 128, True).get_linear_method()
+    w = method.create_weights(4096, 11008, 4096, 11008, torch.float16)
+    want = meta["create_weights_4096x11008"]
+    assert sorted(w) == sorted(want)
+    for name, spec in want.items():
+        p = w[name]
+        assert isinstance(p, torch.nn.Parameter)
+        assert list(p.shape) == spec["shape"] and str(p.dtype) == spec["dtype"]
+        assert p.requires_grad == spec["requires_grad"]
+        got = {k: getattr(p, k) for k in ("input_dim", "output_dim", "packed_dim", "pack_factor") if hasattr(p, k)}
+        assert got == spec["attrs"]
+    errs = meta["create_weights_errors"]
+    assert caught(lambda: method.create_weights(4096, 11004, 4096, 11004, torch.float16)) == errs["n_unaligned"]
+    assert caught(lambda: method.create_weights(4000, 11008, 4000, 11008, torch.float16)) == errs["k_unaligned"]
+
+
+def test_apply_weights_dispatch_and_values(meta, arrays, monkeypatch):
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = AWQConfig(4, 128, True).get_linear_method()
+    weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
+    bias = torch.from_numpy(arrays["apply/bias"])
+    for label, spec in meta["apply_weights"].items():
+        x = torch.from_numpy(arrays[f"apply/{label}/x"])
+        del fake.trace[:]
+        y = method.apply_weights(weights, x, bias if spec["bias"] else None)
+        assert list(y.shape) == spec["out_shape"] and str(y.dtype) == spec["out_dtype"], label
+        ops_called = [t for t in fake.trace if t[0] != "repack"]
+        ref = spec["trace"]
+        assert len(ops_called) == len(ref) == 1, label
+        assert ops_called[0][0] == ref[0][0], label  # same operator chosen at this token count
+        if ref[0][0] == "awq_gemm":
+            assert ops_called[0][1] == ref[0][1] and ops_called[0][2] == ref[0][3], label  # 2-D, contiguous
+        else:
+            assert ops_called[0][1:] == ref[0][1:], label  # (qweight shape, 0, 0, 0)
+        want = arrays[f"apply/{label}/out"].astype(np.float32)
+        assert np.allclose(y.numpy().astype(np.float32), want, rtol=1e-2, atol=1e-3), label
+    # the re-layout happens once per layer, not once per call
+    del fake.trace[:]
+    x = torch.from_numpy(arrays["apply/m1/x"])
+    method.apply_weights(weights, x)
+    method.apply_weights(weights, x)
+    assert [t[0] for t in fake.trace].count("repack") == 0
+    weights["qweight"].add_(0)  # an in-place write (e.g. weight loading) invalidates the packed copy
+    method.apply_weights(weights, x)
+    assert [t[0] for t in fake.trace].count("repack") == 1
+
+
+def test_threshold_none_always_uses_fused_kernel(arrays, monkeypatch):
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = awq_mod.AWQLinearMethod(AWQConfig(4, 128, True), fp16_matmul_threshold=None)
+    weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
+    method.apply_weights(weights, torch.from_numpy(arrays["apply/m256/x"]))
+    assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm"]
+
+
+# --------------------------------------------------------------------------
+# tensor-parallel weight loaders
+# --------------------------------------------------------------------------
+def ckpt(K, N, seed):
+    _, qw, s, qz = orc.make_inputs(1, K, N, 32, seed=seed)
+    return {"qweight": qw, "scales": s, "qzeros": qz}
+
+
+def feed(layer, items):
+    for name, arr, shard in items:
+        p = getattr(layer, name)
+        if shard is None:
+            p.weight_loader(p, torch.from_numpy(arr))
+        else:
+            p.weight_loader(p, torch.from_numpy(arr), shard)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_weight_loaders_match_reference_shards(meta, arrays, monkeypatch, world):
+    g32 = AWQConfig(4, 32, True).get_linear_method()
+    seeds = meta["loader_checkpoint_seeds"]
+    for rank in range(world):
+        monkeypatch.setattr(L, "get_tensor_model_parallel_world_size", lambda: world)
+        monkeypatch.setattr(L, "get_tensor_model_parallel_rank", lambda: rank)
+        tag = f"tp{world}r{rank}"
+
+        def check(label, layer):
+            for name in ("qweight", "scales", "qzeros"):
+                want = arrays[f"loader/{label}/{tag}/{name}"]
+                got = getattr(layer, name).data.numpy()
+                assert got.shape == want.shape and (got.view(np.uint8) == want.view(np.uint8)).all(), \
+                    (label, tag, name)
+
+        ck = ckpt(64, 128, seeds["column"])
+        layer = L.ColumnParallelLinear(64, 128, bias=False, params_dtype=torch.float16, linear_method=g32)
+        feed(layer, [(n, ck[n], None) for n in ck])
+        check("column", layer)
+
+        ck = ckpt(128, 64, seeds["row"])
+        layer = L.RowParallelLinear(128, 64, bias=False, params_dtype=torch.float16, linear_method=g32)
+        feed(layer, [(n, ck[n], None) for n in ck])
+        check("row", layer)
+
+        a, b = ckpt(64, 64, seeds["merged"][0]), ckpt(64, 128, seeds["merged"][1])
+        layer = L.MergedColumnParallelLinear(64, [64, 128], bias=False, params_dtype=torch.float16,
+                                             linear_method=g32)
+        feed(layer, [(n, a[n], 0) for n in a] + [(n, b[n], 1) for n in b])
+        check("merged_split", layer)
+        layer = L.MergedColumnParallelLinear(64, [64, 128], bias=False, params_dtype=torch.float16,
+                                             linear_method=g32)
+        feed(layer, [(n, np.concatenate([a[n], b[n]], axis=1), None) for n in a])
+        check("merged_fused", layer)
+
+        q, k, v = (ckpt(64, 64, seeds["qkv"][0]), ckpt(64, 32, seeds["qkv"][1]), ckpt(64, 32, seeds["qkv"][2]))
+        layer = L.QKVParallelLinear(64, 16, 4, 2, bias=False, params_dtype=torch.float16, linear_method=g32)
+        feed(layer, [(n, q[n], "q") for n in q] + [(n, k[n], "k") for n in k] + [(n, v[n], "v") for n in v])
+        check("qkv_split", layer)
+        layer = L.QKVParallelLinear(64, 16, 4, 2, bias=False, params_dtype=torch.float16, linear_method=g32)
+        feed(layer, [(n, np.concatenate([q[n], k[n], v[n]], axis=1), None) for n in q])
+        check("qkv_fused", layer)
+        want = meta["loaders"][tag]
+        assert layer.num_heads == want["qkv_num_heads"]
+        assert layer.num_kv_heads == want["qkv_num_kv_heads"]
+        assert layer.num_kv_head_replicas == want["qkv_num_kv_head_replicas"]
+        assert layer.output_size == want["qkv_output_size"]
+
+
+def test_layer_conventions(monkeypatch):
+    """forward returns (output, output_bias); skip_bias_add hands the bias back; TP misalignment raises."""
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = AWQConfig(4, 32, True).get_linear_method()
+    ck = ckpt(64, 128, 7)
+    layer = L.ReplicatedLinear(64, 128, bias=True, skip_bias_add=True, params_dtype=torch.float16,
+                               linear_method=method)
+    for n in ck:
+        getattr(layer, n).data.copy_(torch.from_numpy(ck[n]))
+    layer.bias.data.fill_(0.5)
+    x = torch.from_numpy(orc.make_inputs(3, 64, 128, 32, seed=8)[0])
+    out, ob = layer(x)
+    assert ob is layer.bias and out.shape == (3, 128)
+    want = orc.gemm_faithful(x.numpy(), ck["qweight"], ck["scales"], ck["qzeros"])
+    assert np.allclose(out.detach().numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=1e-3)
+    layer2 = L.ReplicatedLinear(64, 128, bias=True, params_dtype=torch.float16, linear_method=method)
+    for n in ck:
+        getattr(layer2, n).data.copy_(torch.from_numpy(ck[n]))
+    layer2.bias.data.fill_(0.5)
+    out2, ob2 = layer2(x)
+    assert ob2 is None
+    assert np.allclose(out2.detach().numpy().astype(np.float32), want.astype(np.float32) + 0.5, rtol=1e-2, atol=2e-3)
+    # Llama-7B down_proj (11008 = 86 groups of 128) cannot be row-split 4 ways (awq.py:84-88)
+    monkeypatch.setattr(L, "get_tensor_model_parallel_world_size", lambda: 4)
+    m128 = AWQConfig(4, 128, True).get_linear_method()
+    with pytest.raises(ValueError, match="input size is not aligned"):
+        L.RowParallelLinear(11008, 4096, bias=False, params_dtype=torch.float16, linear_method=m128)
+    with pytest.raises(ValueError, match="adding bias"):
+        L.RowParallelLinear(1024, 64, bias=True, reduce_results=False, params_dtype=torch.float16,
+                            linear_method=m128)
+    with pytest.raises(AssertionError):
+        L.set_weight_attrs(layer.qweight, {"input_dim": 1})

@@ -63,6 +63,11 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def stream_is_capturing() -> bool:
+    """True while torch's current stream records a HIP graph."""
+    return torch.cuda.is_current_stream_capturing()
+
+
 class _on_device:
     """Makes `device` current for the duration of a call (OptionalCUDAGuard, gemm_kernels.cu:398)."""
 
@@ -197,7 +202,7 @@ def _cached_pack(kernel, scaling_factors, zeros) -> Optional[PackedAWQ]:
     entry = _repack_cache.get(key)
     if entry is not None and entry.matches(tensors):
         return entry.packed
-    if torch.cuda.is_current_stream_capturing():
+    if stream_is_capturing():
         return None  # never re-layout or allocate persistent state inside a graph capture
     if len(_repack_cache) >= _CACHE_LIMIT:
         dead = [k for k, e in _repack_cache.items() if any(r() is None for r in e.refs)]

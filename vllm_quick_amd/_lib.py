@@ -10,6 +10,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_int, c_size_t, c_void_p
 
+# torch first: the PyTorch-ROCm wheel carries its own libamdhip64.so.  Loading it before
+# libw4a16.so makes the dynamic loader bind both to that ONE HIP runtime (same SONAME); in the
+# other order the process ends up with two runtimes and launches fail with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libw4a16.so")
 

@@ -469,6 +469,10 @@ int check_common(int K, int N, int G) {
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
+// hipGetLastError() is sticky per thread: drop whatever an earlier, unrelated call left
+// behind so that launched() reports this library's launches only.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 int launched() {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -602,6 +606,7 @@ int w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const
   if (rc) return rc;
   if ((long long)M * N >= (1LL << 31) || (long long)M * K >= (1LL << 31)) return W4A16_E_TOO_LARGE;
   if (misaligned(scales) || misaligned(out)) return W4A16_E_ALIGN;
+  clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 block(64);
   const int NC = N / 8;
@@ -625,6 +630,7 @@ int w4a16_dequantize_f16(const void* qweight, const void* scales, const void* qz
   const int rc = check_common(K, N, G);
   if (rc) return rc;
   if (misaligned(scales) || misaligned(out)) return W4A16_E_ALIGN;
+  clear_stale_error();
   const size_t total = (size_t)K * (N / 8);
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(dequant_stock_kernel, dim3(blocks), dim3(256), 0,
@@ -640,6 +646,7 @@ int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, vo
   if (rc) return rc;
   if (K % 32) return W4A16_E_SHAPE;
   if (misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
+  clear_stale_error();
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
   const hipStream_t s = static_cast<hipStream_t>(stream);
   {
@@ -672,6 +679,7 @@ int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* p
   if (misaligned(x) || misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
   if (reinterpret_cast<uintptr_t>(out) & 7u) return W4A16_E_ALIGN;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return W4A16_E_ALIGN;
+  clear_stale_error();
   GemmArgs a;
   a.x = (const f16*)x;
   a.pw = (const u32x4*)packed_w;
@@ -702,6 +710,7 @@ int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, voi
   if (!packed_w || !packed_sz || !out) return W4A16_E_NULL;
   const int rc = check_common(K, N, G);
   if (rc) return rc;
+  clear_stale_error();
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
   const size_t total = (size_t)NT * KB * 256;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);

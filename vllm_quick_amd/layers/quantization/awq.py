@@ -1,0 +1,146 @@
+"""AWQ (4-bit weights, fp16 activations) linear method on the MI355X kernels.
+
+Mirror of vllm/model_executor/layers/quantization/awq.py: `AWQConfig` (:12-67)
+and `AWQLinearMethod.create_weights` (:80-141) / `apply_weights` (:143-165) keep
+the reference's parameter names, shapes, dtypes, loader attributes, error
+conditions and the M >= 256 dequantise-then-matmul dispatch.  What differs is
+underneath: the first `apply_weights` on a layer re-orders its weights once into
+libw4a16's MFMA-ordered layout (kept in the layer's weights dict next to the
+stock tensors, the way the reference's GPTQ method keeps `exllama_state`,
+gptq.py:180-186) and later calls go straight to the packed-layout kernel, with
+the bias add folded into its epilogue.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch.nn.parameter import Parameter
+
+from ..._C import ops
+from ..linear import LinearMethodBase, set_weight_attrs
+from .base_config import QuantizationConfig
+
+_PACKED_KEY = "w4a16_packed"
+
+
+class AWQConfig(QuantizationConfig):
+    """Config class for AWQ (https://arxiv.org/abs/2306.00978)."""
+
+    def __init__(self, weight_bits: int, group_size: int, zero_point: bool) -> None:
+        self.weight_bits = weight_bits
+        self.group_size = group_size
+        self.zero_point = zero_point
+        if self.weight_bits != 4:
+            raise ValueError("Currently, only 4-bit weight quantization is supported for "
+                             f"AWQ, but got {self.weight_bits} bits.")
+        self.pack_factor = 32 // self.weight_bits
+
+    def __repr__(self) -> str:
+        return (f"AWQConfig(weight_bits={self.weight_bits}, "
+                f"group_size={self.group_size}, "
+                f"zero_point={self.zero_point})")
+
+    def get_name(self) -> str:
+        return "awq"
+
+    def get_supported_act_dtypes(self) -> List[torch.dtype]:
+        return [torch.half]
+
+    def get_min_capability(self) -> int:
+        # Meaningful for the reference's CUDA kernel only (Turing or newer); kept for API parity.
+        return 75
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return ["quant_config.json", "quantize_config.json"]
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "AWQConfig":
+        weight_bits = cls.get_from_keys(config, ["w_bit", "bits"])
+        group_size = cls.get_from_keys(config, ["q_group_size", "group_size"])
+        zero_point = cls.get_from_keys(config, ["zero_point"])
+        return cls(weight_bits, group_size, zero_point)
+
+    def get_linear_method(self) -> "AWQLinearMethod":
+        return AWQLinearMethod(self)
+
+    def get_scaled_act_names(self) -> List[str]:
+        return ["gelu", "gelu_fast", "gelu_new", "gelu_pytorch_tanh"]
+
+
+class AWQLinearMethod(LinearMethodBase):
+    """Linear method for AWQ.
+
+    Args:
+        quant_config: The AWQ quantization config.
+        fp16_matmul_threshold: token count from which `apply_weights` dequantises the
+            weights and calls `torch.matmul`, as the reference does (256, awq.py:155).
+            `None` always uses the fused W4A16 kernel.
+    """
+
+    def __init__(self, quant_config: AWQConfig, fp16_matmul_threshold: Optional[int] = 256):
+        self.quant_config = quant_config
+        self.fp16_matmul_threshold = fp16_matmul_threshold
+
+    def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
+                       output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
+        group, pack = self.quant_config.group_size, self.quant_config.pack_factor
+        misaligned = ("The {} size is not aligned with the quantized weight shape. "
+                      "This can be caused by too large tensor parallel size.")
+        if input_size_per_partition % group != 0:
+            raise ValueError(misaligned.format("input"))
+        if output_size_per_partition % pack != 0:
+            raise ValueError(misaligned.format("output"))
+
+        def packed_param(rows: int) -> Parameter:
+            p = Parameter(torch.empty(rows, output_size_per_partition // pack, dtype=torch.int32),
+                          requires_grad=False)
+            set_weight_attrs(p, {"input_dim": 0, "output_dim": 1, "packed_dim": 1, "pack_factor": pack})
+            return p
+
+        qweight = packed_param(input_size_per_partition)
+        qzeros = packed_param(input_size_per_partition // group)
+        scales = Parameter(torch.empty(input_size_per_partition // group, output_size_per_partition,
+                                       dtype=params_dtype),
+                           requires_grad=False)
+        set_weight_attrs(scales, {"input_dim": 0, "output_dim": 1})
+        return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
+
+    @staticmethod
+    def _packed(weights: Dict[str, Any]) -> Optional[ops.PackedAWQ]:
+        """The layer's MFMA-ordered weights, (re)built when the stock tensors changed."""
+        stock = (weights["qweight"], weights["scales"], weights["qzeros"])
+        stamp = tuple((t.data_ptr(), t._version) for t in stock)
+        state = weights.get(_PACKED_KEY)
+        if state is not None and state[0] == stamp:
+            return state[1]
+        if ops.stream_is_capturing():
+            return None  # no re-layout inside a graph capture; the stock-layout kernel serves this call
+        packed = ops.awq_repack(*stock)
+        weights[_PACKED_KEY] = (stamp, packed)
+        return packed
+
+    def apply_weights(self, weights: Dict[str, Any], x: torch.Tensor,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        qweight, scales, qzeros = weights["qweight"], weights["scales"], weights["qzeros"]
+        pack_factor = self.quant_config.pack_factor
+        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor, )
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        num_tokens = x.shape[:-1].numel()
+
+        if self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold:
+            dense = ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
+            out = torch.matmul(reshaped_x, dense)
+            if bias is not None:
+                out = out + bias
+            return out.reshape(out_shape)
+
+        packed = self._packed(weights)
+        if packed is None:
+            out = ops.awq_gemm_stock(reshaped_x, qweight, scales, qzeros)
+            if bias is not None:
+                out = out + bias
+        else:
+            out = ops.awq_gemm_packed(reshaped_x, packed, bias=bias)
+        return out.reshape(out_shape)

@@ -1,0 +1,41 @@
+"""Collectives of the tensor-parallel linear layers.
+
+Reference: vllm/model_executor/parallel_utils/communication_op.py:17-69.  The
+reference tries a CUDA-IPC custom kernel, then CuPy-NCCL, then
+torch.distributed; on MI355X the path is torch.distributed over RCCL, whose
+ring/tree/direct choice already fits the point-to-point xGMI mesh.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_parallel_world_size)
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """Sum over the TP group.  In place; callers must still use the return value."""
+    if get_tensor_model_parallel_world_size() == 1:
+        return input_
+    dist.all_reduce(input_, group=get_tensor_model_parallel_group())
+    return input_
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """Concatenate every rank's tensor along `dim` (rank order)."""
+    world = get_tensor_model_parallel_world_size()
+    if world == 1:
+        return input_
+    if not -input_.dim() <= dim < input_.dim():
+        raise AssertionError(f"Invalid dim ({dim}) for input tensor with shape {input_.size()}")
+    dim %= input_.dim()
+    shape = tuple(input_.shape)
+    if not shape:
+        raise AssertionError("cannot all-gather a 0-d tensor")
+    # Concatenated-along-dim-0 form: accepted by both RCCL and gloo.
+    flat = torch.empty((world * shape[0], ) + shape[1:], dtype=input_.dtype, device=input_.device)
+    dist.all_gather_into_tensor(flat, input_.contiguous(), group=get_tensor_model_parallel_group())
+    gathered = flat.view((world, ) + shape)
+    # [world, ..., d, ...] -> [..., world, d, ...] -> [..., world * d, ...]
+    gathered = gathered.movedim(0, dim)
+    return gathered.reshape(shape[:dim] + (world * shape[dim], ) + shape[dim + 1:])
