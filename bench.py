@@ -1,0 +1,346 @@
+"""Benchmark of the W4A16 (AWQ) GEMM path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload: the single 4096 x 11008 group-128 W4A16 linear of the kernel-only sweep
+("configs[1]" of BASELINE.json), synthetic seeded inputs already resident in HBM.
+One STEP = that linear applied twice to a batch of M = 128 tokens, once per tensor-parallel
+sharding of the layer over the N ranks:
+  * column-parallel: every rank multiplies by its N/p output columns, no collective;
+  * row-parallel   : every rank multiplies its K/p input slice, then one RCCL all-reduce
+                     of the [M, 11008] partial products over xGMI.
+At N = 1 both are the unsharded GEMM.  `value` = 2 * (2 M K N) flops per step / step time,
+whole job, i.e. the TFLOP/s of the 4096 x 11008 layer ("strong" scaling: the layer is fixed).
+16 distinct weight sets are rotated (375 MB > the 256 MB Infinity Cache) so weights come
+from HBM on every launch.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline       dominant kernel of the timed region (M = 128, MFMA-bound),
+  roofline_m1    the M = 1 decode launch of the same layer (HBM-bound), N = 1 only,
+  sweep          per-M kernel times of the whole M sweep, N = 1 only,
+  cpu_baseline   torch.matmul(x, dequant(W)) with the oracle's dequantiser on the host cores, N = 1 only,
+  tp             column-/row-parallel halves of the step timed separately.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vllm_quick_amd._C import ops  # noqa: E402  (raises if libw4a16.so is missing)
+
+K_IN, N_OUT, GROUP = 4096, 11008, 128
+M_HEADLINE = 128
+NBUF = 16
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E, vendor figure
+PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16 matrix, vendor figure
+
+
+def algorithmic_bytes(M, K, N, G):
+    """qweight + scales + qzeros + x + out, each touched once."""
+    return K * N // 2 + (K // G) * N * 2 + (K // G) * (N // 8) * 4 + 2 * M * K + 2 * M * N
+
+
+def make_weights(K, N, G, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), generator=g, device=device, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2**31, 2**31 - 1, (K // G, N // 8), generator=g, device=device,
+                       dtype=torch.int64).to(torch.int32)
+    s = (torch.rand((K // G, N), generator=g, device=device) * (2e-2 - 1e-3) + 1e-3).half()
+    return qw, s, qz
+
+
+def make_x(M, K, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return (torch.randn((M, K), generator=g, device=device) * 0.25).half()
+
+
+def graph_of(fns, stream):
+    """Capture one launch of each callable into a HIP graph on `stream`."""
+    with torch.cuda.stream(stream):
+        for f in fns:
+            f()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in fns:
+                f()
+    return g
+
+
+def time_launches(fns, stream, launches, warmup):
+    """Mean microseconds per launch over `launches` launches (graph replays of len(fns) launches
+    each, rotating the weight sets), timed with HIP events recorded on the launch stream."""
+    g = graph_of(fns, stream)
+    reps = max(1, launches // len(fns))
+    with torch.cuda.stream(stream):
+        for _ in range(max(1, warmup // len(fns))):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            g.replay()
+        e1.record(stream)
+        e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * len(fns))
+
+
+def cpu_baseline(M, K, N, G):
+    """torch.matmul(x, dequant(W)) on the host cores: the oracle's dequantiser (numpy) followed by
+    torch's fp32 CPU matmul, rounded to fp16.  Whole 4096 x 11008 layer, median of 3."""
+    import numpy as np
+    from oracle import awq_oracle as orc
+    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=0)
+    t_dq, t_mm = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        w = orc.dequantize(qw, s, qz)
+        t1 = time.perf_counter()
+        y = torch.matmul(torch.from_numpy(x).float(), torch.from_numpy(w).float()).half()
+        t2 = time.perf_counter()
+        t_dq.append(t1 - t0)
+        t_mm.append(t2 - t1)
+    dq, mm = float(np.median(t_dq)), float(np.median(t_mm))
+    flops = 2.0 * M * K * N
+    return {
+        "value": flops / (dq + mm) * 1e-12,
+        "unit": "TFLOP/s",
+        "cores": torch.get_num_threads(),
+        "host_cpus": os.cpu_count(),
+        "kind": "port",
+        "sample": f"whole {K}x{N} g{G} layer at M={M}, dequant+matmul, median of 3",
+        "dequant_s": dq,
+        "matmul_s": mm,
+        "matmul_only_tflops": flops / mm * 1e-12,
+        "checksum": float(y.float().abs().sum()),
+    }
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes), if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    local %= max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
+    p = world
+    K, N, G, M = K_IN, N_OUT, GROUP, M_HEADLINE
+    if N % (8 * p) or (K // p) % G:
+        raise SystemExit(f"{K}x{N} g{G} cannot be sharded {p} ways")
+
+    # Weight sets: column shards [K, N/p] and row shards [K/p, N] of the same layers.
+    col, row = [], []
+    for i in range(NBUF):
+        qw, s, qz = make_weights(K, N, G, seed=i, device=device)
+        nc, n = N // 8 // p, N // p
+        col.append(ops.awq_repack(qw[:, rank * nc:(rank + 1) * nc].contiguous(),
+                                  s[:, rank * n:(rank + 1) * n].contiguous(),
+                                  qz[:, rank * nc:(rank + 1) * nc].contiguous()))
+        if p == 1:
+            row.append(col[-1])
+        else:
+            kk, gg = K // p, K // G // p
+            row.append(ops.awq_repack(qw[rank * kk:(rank + 1) * kk].contiguous(),
+                                      s[rank * gg:(rank + 1) * gg].contiguous(),
+                                      qz[rank * gg:(rank + 1) * gg].contiguous()))
+        del qw, s, qz
+    if rank == 0:
+        print(f"[bench] {NBUF} weight sets packed on {world} rank(s)", file=sys.stderr, flush=True)
+    x_full = make_x(M, K, seed=1234, device=device)
+    x_row = x_full[:, rank * (K // p):(rank + 1) * (K // p)].contiguous()
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream(device=device)
+    group = dist.group.WORLD if world > 1 else None
+
+    def all_reduce(y):
+        if args.backend == "nccl":
+            dist.all_reduce(y, group=group)  # RCCL, in place, ordered after the GEMM on this stream
+        else:  # rehearsal backends (gloo): reduce a host copy
+            h = y.cpu()
+            dist.all_reduce(h, group=group)
+            y.copy_(h)
+
+    def step(i):
+        ops.awq_gemm_packed(x_full, col[i % NBUF])  # column-parallel: no collective
+        y = ops.awq_gemm_packed(x_row, row[i % NBUF])  # row-parallel partial product
+        if world > 1:
+            all_reduce(y)
+        return y
+
+    # ---- timed region: exactly `steps` steps, barrier + synchronize on both sides ----------
+    # On one GPU the steps are replayed from a HIP graph (NBUF steps per replay, the remainder
+    # launched directly) so that host launch cost cannot bound a ~10 us kernel; with a collective
+    # in the step they are launched directly.
+    graph = None
+    if world == 1:
+        graph = graph_of([(lambda i=i: step(i)) for i in range(NBUF)], stream)
+
+    def run_steps(n):
+        done = 0
+        if graph is not None:
+            while done + NBUF <= n:
+                graph.replay()
+                done += NBUF
+        for i in range(done, n):
+            step(i)
+
+    with torch.cuda.stream(stream):
+        run_steps(args.warmup)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    flops_step = 2 * (2.0 * M * K * N)
+    value = flops_step / (ms_per_step * 1e-3) * 1e-12
+
+    # ---- the two halves of the step, and the kernel alone, via graph replays + HIP events ---
+    if rank == 0:
+        print(f"[bench] timed region done: {ms_per_step:.4f} ms/step", file=sys.stderr, flush=True)
+    launches = max(NBUF, args.steps)
+    col_us = time_launches([(lambda i=i: ops.awq_gemm_packed(x_full, col[i])) for i in range(NBUF)], stream,
+                           launches, args.warmup)
+    row_us = time_launches([(lambda i=i: ops.awq_gemm_packed(x_row, row[i])) for i in range(NBUF)], stream,
+                           launches, args.warmup)
+    tp = {"column_gemm_us": col_us, "row_gemm_us": row_us}
+    if world > 1:
+        with torch.cuda.stream(stream):
+            y = ops.awq_gemm_packed(x_row, row[0])
+            for _ in range(8):
+                all_reduce(y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(64):
+                all_reduce(y)
+            e1.record(stream)
+            e1.synchronize()
+        tp["all_reduce_us"] = e0.elapsed_time(e1) * 1e3 / 64
+        tp["all_reduce_bytes"] = 2 * M * N
+
+    out = {
+        "metric": "W4A16 GEMM TFLOPS (4096x11008 g128, M=128)",
+        "value": value,
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"kernel-only W4A16 linear {K}x{N} group {G}, M={M}; step = column-parallel GEMM + "
+                        f"row-parallel GEMM (+ all-reduce), {NBUF} rotating weight sets",
+            "M": M, "K": K, "N": N, "group_size": G,
+            "parallelism": f"tp{world}",
+        },
+        "tp": tp,
+    }
+
+    # roofline of the dominant kernel of the timed region: the M=128 GEMM on this rank's column shard
+    # (at N=1 the whole layer).  Algorithmic flops per launch / mean launch duration.
+    traffic = load_traffic()
+    n_local = N // p
+    flops_launch = 2.0 * M * K * n_local
+    out["roofline"] = {
+        "kernel": "gemm_packed_kernel (M=128)",
+        "bound": "mfma",
+        "achieved": flops_launch / col_us * 1e-6,
+        "peak": PEAK_F16_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": flops_launch / col_us * 1e-6 / PEAK_F16_TFLOPS,
+        "traffic": traffic.get("m128_hbm_bytes_per_launch") if p == 1 else None,
+        "algorithmic_bytes": algorithmic_bytes(M, K, n_local, G),
+        "launch_us": col_us,
+    }
+
+    if world == 1 and rank == 0:
+        if not args.no_sweep:
+            sweep = {}
+            for m in (1, 8, 16, 32, 128, 512):
+                xm = make_x(m, K, seed=m, device=device)
+                us = time_launches([(lambda i=i: ops.awq_gemm_packed(xm, col[i])) for i in range(NBUF)], stream,
+                                   launches, args.warmup)
+                by, fl = algorithmic_bytes(m, K, N, G), 2.0 * m * K * N
+                sweep[str(m)] = {"us": us, "GBps": by / us * 1e-3, "TFLOPs": fl / us * 1e-6,
+                                 "hbm_frac": by / us * 1e-3 / PEAK_HBM_GBPS, "mfma_frac": fl / us * 1e-6 / PEAK_F16_TFLOPS}
+            out["sweep"] = sweep
+            m1 = sweep["1"]
+            out["roofline_m1"] = {
+                "kernel": "gemm_packed_kernel (M=1)",
+                "bound": "hbm",
+                "achieved": m1["GBps"],
+                "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s",
+                "frac": m1["hbm_frac"],
+                "traffic": traffic.get("m1_hbm_bytes_per_launch"),
+                "algorithmic_bytes": algorithmic_bytes(1, K, N, G),
+                "launch_us": m1["us"],
+            }
+            # context: the dense fp16 GEMM torch dispatches to (hipBLASLt) on the same shape
+            wd = torch.randn((K, N), device=device).half()
+            us = time_launches([(lambda: torch.matmul(x_full, wd))] * 4, stream, 64, 8)
+            out["context"] = {"dense_fp16_matmul_m128_us": us, "dense_fp16_matmul_m128_tflops": 2.0 * M * K * N / us * 1e-6}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(M, K, N, G)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
