@@ -91,12 +91,13 @@ size_t w4a16_packed_sz_bytes(int K, int N, int G);
 
 /*
  * One-time re-layout of the stock tensors into the private format
- *   packed_w  : [ceil(N/16)][ceil(K/128)][64 lanes][4] uint32 - word j of lane l of block
+ *   packed_w  : [ceil(N/16)][KB][64 lanes][4] uint32, KB = ceil(K/512)*4 - word j of lane l of block
  *               (nt, kb) holds k = 128 kb + 32 j + 8 (l >> 4) + i (i = 0..7, nibble order
  *               {0,4,1,5,2,6,3,7}) of column n = 16 nt + (l & 15): one 16-byte load per lane
  *               is four ready-made 16x16x32 MFMA A-operand fragments.
  *   packed_sz : [ceil(N/16)][K/G][16] uint32 - low half fp16 scale, high half fp16 -(1024 + zero).
- * Padding (n >= N, k >= K) is zero-filled.  The stock tensors are not modified.
+ * Padding columns (n >= N) are zero words with zero scale; padding k (k >= K) repeats the last
+ * group's zero point, i.e. dequantises to exactly 0.  The stock tensors are not modified.
  */
 int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, void* packed_w,
                  void* packed_sz, int K, int N, int G, void* stream);
@@ -120,6 +121,17 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
 int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* packed_sz,
                               const void* bias, void* out, int M, int K, int N, int G, int mt,
                               int t, int waves, void* stream);
+
+/*
+ * The LDS-staged variant of the same GEMM with an explicit launch shape, for tuning and tests
+ * (w4a16_gemm_packed_f16 picks it by itself when it is the faster one): a workgroup owns
+ * mt x (nw * t) 16x16 output tiles; its nw * kw wavefronts form kw groups that split K, the nw
+ * wavefronts of a group split the columns and share the group's activation slab through LDS.
+ * Built combinations only; others return W4A16_E_SHAPE.
+ */
+int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                                    const void* bias, void* out, int M, int K, int N, int G, int mt,
+                                    int t, int nw, int kw, void* stream);
 
 /*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16

@@ -81,7 +81,7 @@ def time_graph(fn_list, iters=20):
     return e0.elapsed_time(e1) * 1e3 / (iters * len(fn_list))
 
 
-def sweep(K=4096, N=11008, G=128, nbuf=16, only_m=None):
+def sweep(K=4096, N=11008, G=128, nbuf=16, only_m=None, cfg_override=None):
     print(f"timing sweep K={K} N={N} G={G}, {nbuf} rotating weight sets")
     packs = []
     for i in range(nbuf):
@@ -102,6 +102,8 @@ def sweep(K=4096, N=11008, G=128, nbuf=16, only_m=None):
     for M, cfgs in cfg_by_m.items():
         if only_m and M not in only_m:
             continue
+        if cfg_override:
+            cfgs = cfg_override
         x = (torch.randn(M, K, device=dev) * 0.25).half()
         by = wbytes + 2 * M * K + 2 * M * N
         fl = 2.0 * M * K * N
@@ -126,12 +128,14 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--only-m", type=str, default="")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cfgs", type=str, default="", help="e.g. 4,6,8;8,3,8")
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
     ok = True
     t0 = time.time()
+    cfgo = [tuple(int(v) for v in c.split(",")) for c in a.cfgs.split(";")] if a.cfgs else None
     if a.no_parity:
-        sweep(only_m=[int(v) for v in a.only_m.split(",")] if a.only_m else None)
+        sweep(only_m=[int(v) for v in a.only_m.split(",")] if a.only_m else None, cfg_override=cfgo)
         return 0
     ok &= check_shape(1, 256, 128, 128, cfgs=[None, (1, 1, 16), (1, 2, 8), (1, 1, 4)])
     ok &= check_shape(3, 256, 192, 64, cfgs=[None, (1, 3, 16), (1, 4, 4)])

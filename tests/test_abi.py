@@ -50,8 +50,9 @@ def test_packed_sizes(lib):
     # 4096 x 11008: same bytes as the stock qweight; 4 bytes per (group, column) of scale+zero
     assert L.w4a16_packed_weight_bytes(4096, 11008) == 4096 * 11008 // 2
     assert L.w4a16_packed_sz_bytes(4096, 11008, 128) == 32 * 11008 * 4
-    # padding to 16 columns x 128 k blocks
-    assert L.w4a16_packed_weight_bytes(96, 40) == 3 * 1 * 1024
+    # padding to 16 columns x (a multiple of 4) 128-k blocks
+    assert L.w4a16_packed_weight_bytes(96, 40) == 3 * 4 * 1024
+    assert L.w4a16_packed_weight_bytes(11008, 4096) == 256 * 88 * 1024
     assert L.w4a16_packed_sz_bytes(96, 40, 32) == 3 * 3 * 16 * 4
     assert L.w4a16_packed_weight_bytes(0, 8) == 0
     assert L.w4a16_packed_sz_bytes(100, 8, 32) == 0

@@ -82,6 +82,10 @@ class CABI:
         if cfg is None:
             rc = self.lib.w4a16_gemm_packed_f16(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b, out.data_ptr(), M, K, N,
                                                 G, self.stream())
+        elif len(cfg) == 4:
+            rc = self.lib.w4a16_gemm_packed_f16_tiled_cfg(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b,
+                                                          out.data_ptr(), M, K, N, G, cfg[0], cfg[1], cfg[2], cfg[3],
+                                                          self.stream())
         else:
             rc = self.lib.w4a16_gemm_packed_f16_cfg(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b, out.data_ptr(), M,
                                                     K, N, G, cfg[0], cfg[1], cfg[2], self.stream())
@@ -161,14 +165,17 @@ def test_ragged_m(abi, cuda, M):
     assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"M={M}")
 
 
-CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 16), (1, 6, 16), (1, 1, 8), (1, 3, 8), (1, 8, 8), (1, 1, 4),
-        (1, 4, 4), (2, 1, 16), (2, 4, 16), (2, 3, 8), (2, 6, 8), (2, 3, 4), (4, 1, 8), (4, 3, 8), (4, 6, 8),
-        (4, 3, 4), (8, 1, 8), (8, 3, 8), (8, 1, 4), (8, 3, 4)]
+CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 8), (1, 6, 8), (1, 1, 8), (1, 3, 8), (1, 8, 8), (1, 1, 4),
+        (1, 4, 4), (2, 1, 16), (2, 4, 8), (2, 3, 8), (2, 6, 8), (2, 3, 4), (4, 1, 8), (4, 3, 8), (4, 6, 8),
+        (4, 3, 4), (8, 1, 8), (8, 3, 8), (8, 1, 4), (8, 3, 4),
+        # LDS-staged kernel: (mt, t, nw, kw)
+        (4, 3, 2, 4), (4, 3, 4, 2), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (2, 3, 2, 4), (2, 3, 1, 4),
+        (8, 3, 2, 2), (8, 3, 1, 2), (4, 6, 1, 4), (2, 6, 1, 4)]
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
 def test_every_launch_shape(abi, cuda, G):
-    M, K, N = 37, 1280, 400  # 3 row tiles, 10 k-blocks, 25 column tiles (ragged against every T)
+    M, K, N = 85, 1280, 400  # 6 row tiles (ragged), 10 k-blocks, 25 column tiles (ragged against every T)
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=G)
     want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
     tx, tqw, ts, tqz = [dev_t(a, cuda) for a in (x, qw, s, qz)]

@@ -16,7 +16,8 @@ from ctypes import c_char_p, c_int, c_size_t, c_void_p
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libw4a16.so")
+# W4A16_LIBRARY points at another build of the same ABI (kernel experiments); default: the in-tree build.
+LIB_PATH = os.environ.get("W4A16_LIBRARY") or os.path.join(_HERE, "csrc", "libw4a16.so")
 
 ABI_VERSION = 1
 
@@ -32,6 +33,7 @@ SYMBOLS = {
     "w4a16_repack": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "w4a16_gemm_packed_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "w4a16_gemm_packed_f16_cfg": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "w4a16_gemm_packed_f16_tiled_cfg": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 

@@ -65,21 +65,46 @@ __device__ __forceinline__ SZ expand_sz(uint32_t w) {
   return r;
 }
 
+// Constants of the int4 -> fp16 conversion, kept in registers the compiler cannot see through:
+// gfx950 VOP3 takes no literal operand, so with compile-time constants `(w & mask) | magic`
+// becomes v_and_b32 + v_or_b32 (two literals); from registers it is one v_and_or_b32.
+struct DqConst {
+  uint32_t lo, hi;  // nibble masks (SGPRs)
+  uint32_t magic;   // half2 {1024, 1024} (VGPR: a VALU op reads at most one SGPR)
+  f16x2 sixteenth;
+};
+
+__device__ __forceinline__ DqConst make_dq_const() {
+  DqConst c;
+  c.lo = kLoMask;
+  c.hi = kHiMask;
+  c.magic = kMagic;
+  asm volatile("" : "+s"(c.lo), "+s"(c.hi));
+  asm volatile("" : "+v"(c.magic));
+  c.sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
+  return c;
+}
+
 // One packed word (8 k of one column) -> 8 fp16 weights in k order.
 // q - z is formed exactly, then rounded once in the multiply by the scale:
 // the same value as sub.f16x2 + fma.rn.f16x2 in gemm_kernels.cu:153-160.
-__device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c) {
+// 13 VALU instructions per word: shift, 4 and-or, 2 add, 2 fma, 4 mul.
+__device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c, const DqConst& k) {
   const uint32_t t = w >> 8;
-  const f16x2 h0 = as_h2((w & kLoMask) | kMagic);
-  const f16x2 h1 = as_h2((w & kHiMask) | kMagic);
-  const f16x2 h2 = as_h2((t & kLoMask) | kMagic);
-  const f16x2 h3 = as_h2((t & kHiMask) | kMagic);
-  const f16x2 sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
+  const f16x2 h0 = as_h2((w & k.lo) | k.magic);
+  const f16x2 h1 = as_h2((w & k.hi) | k.magic);
+  const f16x2 h2 = as_h2((t & k.lo) | k.magic);
+  const f16x2 h3 = as_h2((t & k.hi) | k.magic);
   const f16x2 d0 = (h0 + c.nz1) * c.s;
-  const f16x2 d1 = (h1 * sixteenth + c.nz2) * c.s;
+  const f16x2 d1 = (h1 * k.sixteenth + c.nz2) * c.s;
   const f16x2 d2 = (h2 + c.nz1) * c.s;
-  const f16x2 d3 = (h3 * sixteenth + c.nz2) * c.s;
+  const f16x2 d3 = (h3 * k.sixteenth + c.nz2) * c.s;
   return f16x8{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
+}
+
+__device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c) {
+  const DqConst k = {kLoMask, kHiMask, kMagic, f16x2{(f16)0.0625f, (f16)0.0625f}};
+  return dequant_word(w, c, k);
 }
 
 // ---------------------------------------------------------------------------
@@ -107,6 +132,7 @@ struct GemmArgs {
   f16* out;
   int M, K, N, G;
   int NT, KB, NG;
+  int KBS;  // 128-k blocks per column tile in the packed layout (KB rounded up to a multiple of 4)
 };
 
 // MT : 16-row tiles of the output per workgroup
@@ -134,7 +160,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
   for (int t = 0; t < T; ++t) {
     // Tiles past the end re-read the last tile (valid memory); their results are dropped.
     const int nt = min(nt0 + t, a.NT - 1);
-    wp[t] = a.pw + (size_t)nt * a.KB * 64 + lane;
+    wp[t] = a.pw + (size_t)nt * a.KBS * 64 + lane;
     szp[t] = a.psz + (size_t)nt * a.NG * 16 + n16;
   }
   // Rows past M re-read row M-1: output row m depends on x row m only, and rows >= M
@@ -151,22 +177,18 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const DqConst dqc = make_dq_const();
 
+  // For small row counts the x fragments of a whole block (4 k-steps) travel with the block's
+  // weights: every load of a block is then issued up front, oldest-needed first (x from L2, the
+  // scale/zero words, then the weight stream from HBM), and nothing is loaded inside the
+  // compute phase.  For larger MT that would cost 16 * MT registers per buffer, so x fragments
+  // are fetched one k-step ahead instead.
+  constexpr bool XPRE = (MT <= 2);
   struct Block {
-    u32x4 q[T];
+    f16x8 x[XPRE ? 4 : 1][MT];
     uint32_t sz[T][NSZ];
-  };
-
-  auto load_block = [&](int kb, Block& b) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) b.q[t] = __builtin_nontemporal_load(wp[t] + (size_t)kb * 64);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int s = 0; s < NSZ; ++s) {
-        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
-        b.sz[t][s] = szp[t][g * 16];
-      }
+    u32x4 q[T];
   };
 
   // k-steps past K (K not a multiple of 128, or the prefetch after the last block)
@@ -177,41 +199,68 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
     for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f16x8*>(xp[mt] + ke);
   };
 
+  auto load_block = [&](int kb, Block& b) {
+    if constexpr (XPRE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) load_x(kb * 128 + j * 32, b.x[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        b.sz[t][s] = szp[t][g * 16];
+      }
+#pragma unroll
+    for (int t = 0; t < T; ++t) b.q[t] = __builtin_nontemporal_load(wp[t] + (size_t)kb * 64);
+    // The scheduler must not sink these loads into the compute phase that follows.
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // One 128-k block: 4 k-steps of (T dequantised A fragments) x (MT x fragments).
-  // `xf` holds the x fragments of this block's first k-step on entry and those of
+  // Without XPRE, `xf` holds the x fragments of this block's first k-step on entry and those of
   // block `kb_next`'s first k-step on exit (loaded one k-step ahead throughout).
   auto compute_block = [&](int kb, int kb_next, const Block& b, f16x8 (&xf)[MT]) {
     SZ c[T];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x8 xn[MT];
-      const int knext = (j < 3) ? kb * 128 + (j + 1) * 32 : kb_next * 128;
-      load_x(knext, xn);
+      if constexpr (!XPRE) {
+        const int knext = (j < 3) ? kb * 128 + (j + 1) * 32 : kb_next * 128;
+        load_x(knext, xn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (j % SZS == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) c[t] = expand_sz(b.sz[t][j / SZS]);
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const f16x8 af = dequant_word(b.q[t][j], c[t]);
+        const f16x8 af = dequant_word(b.q[t][j], c[t], dqc);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (XPRE)
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b.x[j][mt], acc[t][mt], 0, 0, 0);
+          else
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+        }
       }
+      if constexpr (!XPRE) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[mt] = xn[mt];
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = xn[mt];
+      }
     }
   };
 
-  // K loop, weights double-buffered one block ahead.  Blocks past KB are never
-  // computed; `kb_next * 128 >= K` makes their x prefetch a zero fill.
+  // K loop, blocks double-buffered one block ahead.  Blocks past KB are never computed;
+  // `kb_next * 128 >= K` turns the x prefetch past the end into a re-read of k = 0.
   {
     Block b0, b1;
     f16x8 xf[MT];
     int kb = w;
     if (kb < a.KB) {
+      if constexpr (!XPRE) load_x(kb * 128, xf);
       load_block(kb, b0);
-      load_x(kb * 128, xf);
     }
     while (kb < a.KB) {
       int kn = kb + W;
@@ -272,6 +321,207 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
 #pragma unroll
       for (int s = 1; s < LIVE; ++s) v += red[(s * TM + i) * 64 + lane];
       store_tile(i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GEMM on the private layout, activations staged through LDS (M > 32)
+// ---------------------------------------------------------------------------
+// A workgroup owns MT x (NW * T) output tiles over the whole of K.  Its NW * KW waves form
+// KW K-groups (group kg takes 128-k blocks kg, kg + KW, ...) of NW waves that split the
+// workgroup's columns.  The [MT*16 rows] x [128 k] activation slab of a K-group's block is
+// fetched ONCE per workgroup with full-line coalesced loads (each wave a share), parked in LDS
+// (XOR-swizzled 256-byte rows, double buffered) and read back as MFMA B fragments by the NW
+// waves of the group; weights still go HBM -> VGPR -> matrix core with no LDS round trip.
+// Against the streaming kernel this removes the fragment-shaped global loads of x (16 rows x
+// 64 B per instruction, every 128-byte line fetched twice) that bound it at M >= 64.
+//
+// Load order per block iteration: next block's x share, then the weights two blocks ahead.
+// Vector-memory returns are counted in order, so this gives the L2-resident x one block and
+// the HBM weight stream two blocks of cover.
+template <int MT, int T, int NW, int KW, int SZS>
+__global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs a, int n_slices,
+                                                                   int m_blocks) {
+  constexpr int NWAVES = NW * KW;
+  constexpr int NSZ = 4 / SZS;
+  constexpr int ROWS = MT * 16;
+  constexpr int SLAB = ROWS * 256;                       // bytes: ROWS x 128 k of fp16
+  constexpr int XLOADS = (ROWS / 4 + NW - 1) / NW;       // 16-byte loads per lane per slab share
+  static_assert(ROWS % (4 * NW) == 0, "each wave of a K-group loads whole 4-row pieces");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = w / NW, nw = w % NW;
+  const int n16 = lane & 15;
+  const int kq = lane >> 4;
+
+  // Workgroups that share an XCD's L2 are those whose ids are equal mod 8.  Give the m_blocks
+  // row-blocks of one column slice ids 8 apart, so their weight reads meet in one L2.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int slice = (idx / m_blocks) * 8 + xcd;
+  const int mb = idx % m_blocks;
+  if (slice >= n_slices) return;  // whole workgroup: no barrier is skipped by a subset
+  const int nt0 = (slice * NW + nw) * T;
+  const int m0 = mb * ROWS;
+
+  const u32x4* wp[T];
+  const uint32_t* szp[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int nt = min(nt0 + t, a.NT - 1);
+    wp[t] = a.pw + (size_t)nt * a.KBS * 64 + lane;
+    szp[t] = a.psz + (size_t)nt * a.NG * 16 + n16;
+  }
+
+  // This wave's share of a slab: pieces of 4 rows x 256 B; lane l -> row 4p + (l >> 4), chunk l & 15.
+  const f16* xsrc[XLOADS];
+  int xdst[XLOADS];
+#pragma unroll
+  for (int p = 0; p < XLOADS; ++p) {
+    const int row = (nw * XLOADS + p) * 4 + kq;
+    const int grow = min(m0 + row, a.M - 1);
+    xsrc[p] = a.x + (size_t)grow * a.K + n16 * 8;
+    xdst[p] = kg * SLAB + row * 256 + ((n16 ^ (row & 15)) << 4);
+  }
+  // B fragment of row tile mt, k-step j: row 16 mt + n16, 16-byte chunk 4 j + kq of the row.
+  int xfrag[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xfrag[mt] = kg * SLAB + (mt * 16 + n16) * 256;
+
+  f32x4 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const DqConst dqc = make_dq_const();
+
+  struct WBlock {
+    uint32_t sz[T][NSZ];
+    u32x4 q[T];
+  };
+#ifndef W4A16_DBG
+#define W4A16_DBG 0
+#endif
+  auto load_w = [&](int kb, WBlock& b) {
+    if ((W4A16_DBG & 2) && kb != kg) return;
+    const int kbe = min(kb, a.KBS - 1);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min((kbe * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        b.sz[t][s] = szp[t][g * 16];
+      }
+    // Default cache policy: the row-blocks of a column slice run side by side on one XCD and the
+    // later ones are meant to find these lines in its L2 (a non-temporal load would drop them).
+#pragma unroll
+    for (int t = 0; t < T; ++t) b.q[t] = wp[t][(size_t)kbe * 64];
+  };
+  auto load_xshare = [&](int kb, u32x4 (&xr)[XLOADS]) {
+    // chunks past K (K % 128 != 0 or a block past the end) re-read k = 0: their weights are zero
+    if ((W4A16_DBG & 1) && kb != kg) return;
+    const int k = kb * 128 + n16 * 8;
+    const int koff = (k < a.K) ? kb * 128 : -(n16 * 8);
+#pragma unroll
+    for (int p = 0; p < XLOADS; ++p) xr[p] = *reinterpret_cast<const u32x4*>(xsrc[p] + koff);
+  };
+  auto store_xshare = [&](int buf, const u32x4 (&xr)[XLOADS]) {
+#pragma unroll
+    for (int p = 0; p < XLOADS; ++p)
+      *reinterpret_cast<u32x4*>(smem_raw + buf * (KW * SLAB) + xdst[p]) = xr[p];
+  };
+  auto compute = [&](int buf, const WBlock& b) {
+    SZ c[T];
+    const unsigned char* base = smem_raw + buf * (KW * SLAB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 xf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if ((W4A16_DBG & 16) && j > 0) {
+          xf[mt] = __builtin_bit_cast(f16x8, b.q[0]);
+          continue;
+        }
+        xf[mt] = *reinterpret_cast<const f16x8*>(base + xfrag[mt] + (((4 * j + kq) ^ n16) << 4));
+      }
+      if (j % SZS == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) c[t] = expand_sz(b.sz[t][j / SZS]);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const f16x8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(f16x8, b.q[t]) : dequant_word(b.q[t][j], c[t], dqc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (W4A16_DBG & 4) {
+            acc[t][mt][0] += (float)af[mt & 7] * (float)xf[mt][j];
+            continue;
+          }
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // All K-groups run KBS / KW iterations in lockstep (KBS is a multiple of 4 >= KW; blocks past K
+  // hold zero weights), and nothing in the steady-state loop is conditional: a load issued under
+  // a branch makes hipcc's wait-count bookkeeping pessimistic and drains the prefetches every
+  // iteration.  The three weight buffers are named statically (a register that a load is still
+  // writing cannot be renamed by a move), hence the loop is unrolled by 3 with a peeled tail.
+  const int iters = (W4A16_DBG & 32) ? 0 : a.KBS / KW;
+  WBlock w0, w1, w2;
+  u32x4 xr[XLOADS];
+  auto phase = [&](int i, const WBlock& cur, WBlock& ahead) {
+    const int kb = kg + i * KW;
+    load_xshare(kb + KW, xr);
+    load_w(kb + 2 * KW, ahead);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(i & 1, cur);
+    store_xshare((i + 1) & 1, xr);
+    __syncthreads();
+  };
+  load_xshare(kg, xr);
+  load_w(kg, w0);
+  load_w(kg + KW, w1);
+  store_xshare(0, xr);
+  __syncthreads();
+  int it = 0;
+  for (; it + 3 <= iters; it += 3) {
+    phase(it, w0, w2);
+    phase(it + 1, w1, w0);
+    phase(it + 2, w2, w1);
+  }
+  if (it < iters) {
+    phase(it, w0, w2);
+    if (it + 1 < iters) phase(it + 1, w1, w0);
+  }
+
+  // Reduce the KW partial sums of every output tile through LDS (the staging buffers are free
+  // now: the loop ended on a barrier) and store.
+  constexpr int TM = T * MT;
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+  if (W4A16_DBG & 64) {
+    if (acc[0][0][0] == 123.f) a.out[0] = (f16)1.0f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) red[((kg * NW + nw) * TM + i) * 64 + lane] = acc[i / MT][i % MT];
+  __syncthreads();
+  for (int o = w; o < NW * TM; o += NWAVES) {
+    const int onw = o / TM, i = o - onw * TM;
+    f32x4 v = red[(onw * TM + i) * 64 + lane];
+#pragma unroll
+    for (int g = 1; g < KW; ++g) v += red[((g * NW + onw) * TM + i) * 64 + lane];
+    const int t = i / MT, mt = i - t * MT;
+    const int nt = (slice * NW + onw) * T + t;
+    const int n = nt * 16 + kq * 4;
+    const int m = m0 + mt * 16 + n16;
+    if (nt < a.NT && n < a.N && m < a.M) {
+      f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
+      *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
     }
   }
 }
@@ -372,7 +622,7 @@ __global__ void __launch_bounds__(256) dequant_stock_kernel(const uint32_t* __re
 __global__ void __launch_bounds__(256) repack_weight_kernel(const uint32_t* __restrict__ qw,
                                                             const uint32_t* __restrict__ qz,
                                                             uint32_t* __restrict__ pw, int K, int N,
-                                                            int G, int NT, int KB) {
+                                                            int G, int NT, int KB) {  // KB: padded count
   const int NC = N / 8;
   const size_t total = (size_t)NT * KB * 256;
   for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
@@ -458,6 +708,10 @@ thread_local int g_last_hip_error = 0;
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// The packed layout stores a multiple of 4 blocks of 128 k per column tile; the padding holds
+// zero-valued weights (q = z), so kernels whose K-groups take blocks in lockstep never branch.
+inline int padded_kblocks(int K) { return ceil_div(K, 512) * 4; }
+
 int check_common(int K, int N, int G) {
   if (K <= 0 || N <= 0 || G <= 0) return W4A16_E_SHAPE;
   if (N % 8) return W4A16_E_OC_PACK;
@@ -479,6 +733,34 @@ int launched() {
     g_last_hip_error = (int)e;
     return W4A16_E_LAUNCH;
   }
+  return W4A16_OK;
+}
+
+// Validates the arguments of the packed-layout GEMM entry points and fills the kernel argument block.
+int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* packed_sz, const void* bias,
+              void* out, int M, int K, int N, int G) {
+  if (!x || !packed_w || !packed_sz || !out) return W4A16_E_NULL;
+  if (M <= 0) return W4A16_E_SHAPE;
+  const int rc = check_common(K, N, G);
+  if (rc) return rc;
+  if (K % 32) return W4A16_E_SHAPE;
+  if ((long long)M * N >= (1LL << 31) || (long long)M * K >= (1LL << 31)) return W4A16_E_TOO_LARGE;
+  if (misaligned(x) || misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
+  if (reinterpret_cast<uintptr_t>(out) & 7u) return W4A16_E_ALIGN;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return W4A16_E_ALIGN;
+  a->x = (const f16*)x;
+  a->pw = (const u32x4*)packed_w;
+  a->psz = (const uint32_t*)packed_sz;
+  a->bias = (const f16*)bias;
+  a->out = (f16*)out;
+  a->M = M;
+  a->K = K;
+  a->N = N;
+  a->G = G;
+  a->NT = ceil_div(N, 16);
+  a->KB = ceil_div(K, 128);
+  a->KBS = padded_kblocks(K);
+  a->NG = K / G;
   return W4A16_OK;
 }
 
@@ -507,13 +789,55 @@ int launch_packed(const GemmArgs& a, hipStream_t s) {
   return launched();
 }
 
+template <int MT, int T, int NW, int KW>
+int launch_tiled(const GemmArgs& a, hipStream_t s) {
+  constexpr int stage = 2 * KW * MT * 16 * 256;         // double-buffered slabs
+  constexpr int reduce = NW * KW * T * MT * 1024;       // partial tiles
+  constexpr int lds = stage > reduce ? stage : reduce;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (a.KBS % KW) return W4A16_E_SHAPE;
+  const int n_slices = ceil_div(a.NT, NW * T);
+  const int m_blocks = ceil_div(a.M, MT * 16);
+  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  void (*kern)(const GemmArgs, int, int) = nullptr;
+  if (a.G % 128 == 0)
+    kern = gemm_tiled_kernel<MT, T, NW, KW, 4>;
+  else if (a.G == 64)
+    kern = gemm_tiled_kernel<MT, T, NW, KW, 2>;
+  else
+    kern = gemm_tiled_kernel<MT, T, NW, KW, 1>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW * KW), lds, s, a, n_slices, m_blocks);
+  return launched();
+}
+
+// (mt, t, nw, kw) of the LDS-staged kernel
+#define W4A16_FOR_EACH_TILED(X) \
+  X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
+  X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4)
+
+int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s) {
+#define X(MT_, T_, NW_, KW_) \
+  if (mt == MT_ && t == T_ && nw == NW_ && kw == KW_) return launch_tiled<MT_, T_, NW_, KW_>(a, s);
+  W4A16_FOR_EACH_TILED(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
 // (mt, t, waves) -> instantiation.  mt in {1,2,4,8}; t in 1..8 with mt*t <= 24;
 // waves 16 for mt <= 2 (128 VGPRs/lane are enough), 8 for mt >= 4; plus 4/8 for short K.
 #define W4A16_FOR_EACH_CFG(X) \
-  X(1, 1, 16) X(1, 2, 16) X(1, 3, 16) X(1, 4, 16) X(1, 6, 16)             \
+  X(1, 1, 16) X(1, 2, 16) X(1, 3, 16)                                     \
   X(1, 1, 8)  X(1, 2, 8)  X(1, 3, 8)  X(1, 4, 8)  X(1, 6, 8)  X(1, 8, 8)  \
   X(1, 1, 4)  X(1, 2, 4)  X(1, 3, 4)  X(1, 4, 4)                          \
-  X(2, 1, 16) X(2, 2, 16) X(2, 3, 16) X(2, 4, 16)                         \
+  X(2, 1, 16)                                                             \
   X(2, 1, 8)  X(2, 2, 8)  X(2, 3, 8)  X(2, 4, 8)  X(2, 6, 8)              \
   X(2, 1, 4)  X(2, 2, 4)  X(2, 3, 4)                                      \
   X(4, 1, 8)  X(4, 2, 8)  X(4, 3, 8)  X(4, 4, 8)  X(4, 6, 8)              \
@@ -535,33 +859,57 @@ int pow2_floor(int v) {
   return p;
 }
 
-// Default launch shape.  Workgroups own whole columns of the output (no
-// cross-workgroup reduction), so the aim is one workgroup per CU with every
-// CU busy: T = column tiles needed to cover N with ~256 workgroups.
-void choose_cfg(int M, int K, int N, int* mt, int* t, int* waves) {
+// Default launch shape.
+//
+// Workgroups own whole columns of the output (no cross-workgroup reduction), so the aim is about
+// one workgroup per CU with every CU busy.  Up to 32 rows the streaming kernel runs (x fragments
+// straight from L2 into registers); above that the LDS-staged kernel, whose candidates are ranked
+// by a small cost model: rounds of 256 workgroups x tiles per workgroup, penalised for 2-row-tile
+// shapes (the int4 -> fp16 conversion of a weight fragment is then shared by 2 instead of 4
+// matrix instructions) and for half-empty workgroups.
+struct Choice {
+  bool tiled;
+  int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
+};
+
+Choice choose_cfg(int M, int K, int N) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   const int mtiles = ceil_div(M, 16);
-  int MT = mtiles >= 8 ? 8 : mtiles > 2 ? 4 : mtiles;  // 1, 2, 4, 8
-  int Wv = (MT <= 2) ? 16 : 8;
-  while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
-  const int mblocks = ceil_div(mtiles, MT);
   const int cus = 256;
-  // workgroups that fit a CU at once, by wave count (16 waves of <=128 VGPRs)
-  const int per_cu = 16 / Wv;
-  int Tt = ceil_div((long long)NT * mblocks, (long long)cus * per_cu);
-  if (Tt < 1) Tt = 1;
-  if (Tt == 5) Tt = 6;
-  if (Tt == 7) Tt = 8;
-  // largest T instantiated for this (MT, waves): see W4A16_FOR_EACH_CFG
-  int tmax;
-  if (MT == 1) tmax = (Wv == 16) ? 6 : (Wv == 8) ? 8 : 4;
-  else if (MT == 2) tmax = (Wv == 16) ? 4 : (Wv == 8) ? 6 : 3;
-  else if (MT == 4) tmax = (Wv == 8) ? 6 : 3;
-  else tmax = 3;
-  if (Tt > tmax) Tt = tmax;
-  *mt = MT;
-  *t = Tt;
-  *waves = Wv;
+  if (mtiles <= 2) {
+    const int MT = mtiles;
+    int Wv = (MT == 1) ? 16 : 8;
+    while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
+    int Tt = ceil_div(NT, cus);  // one workgroup per CU (registers and LDS admit no second one)
+    if (Tt < 1) Tt = 1;
+    if (Tt == 5) Tt = 6;
+    if (Tt == 7) Tt = 8;
+    // largest T instantiated for this (MT, waves): see W4A16_FOR_EACH_CFG
+    int tmax;
+    if (MT == 1) tmax = (Wv == 16) ? 3 : (Wv == 8) ? 8 : 4;
+    else tmax = (Wv == 16) ? 1 : (Wv == 8) ? 6 : 3;
+    if (Tt > tmax) Tt = tmax;
+    return Choice{false, MT, Tt, Wv, 0};
+  }
+  static const int cand[][4] = {{4, 3, 2, 4}, {4, 3, 4, 2}, {4, 3, 1, 4}, {4, 2, 2, 4},
+                                {2, 3, 2, 4}, {2, 3, 1, 4}};
+  Choice best{true, 4, 3, 2, 4};
+  double best_cost = 1e300;
+  for (const auto& c : cand) {
+    const int mt = c[0], t = c[1], nw = c[2], kw = c[3];
+    if (mtiles <= 4 && mt == 4 && mtiles <= 2) continue;
+    const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt);
+    const double rounds = (double)ceil_div(ctas, cus);
+    double cost = rounds * mt * t * nw;               // matrix work per workgroup
+    cost *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
+    cost *= (nw * kw == 8) ? 1.0 : 1.25;              // 4-wave workgroups: one wave per SIMD
+    cost *= 1.0 + 0.15 / nw;                          // x slab amortised over nw waves
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = Choice{true, mt, t, nw, kw};
+    }
+  }
+  return best;
 }
 
 }  // namespace
@@ -589,7 +937,7 @@ int w4a16_abi_version(void) { return W4A16_ABI_VERSION; }
 
 size_t w4a16_packed_weight_bytes(int K, int N) {
   if (K <= 0 || N <= 0) return 0;
-  return (size_t)ceil_div(N, 16) * ceil_div(K, 128) * 1024;
+  return (size_t)ceil_div(N, 16) * padded_kblocks(K) * 1024;
 }
 
 size_t w4a16_packed_sz_bytes(int K, int N, int G) {
@@ -647,7 +995,7 @@ int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, vo
   if (K % 32) return W4A16_E_SHAPE;
   if (misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
   clear_stale_error();
-  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
+  const int NT = ceil_div(N, 16), KB = padded_kblocks(K), NG = K / G;
   const hipStream_t s = static_cast<hipStream_t>(stream);
   {
     const size_t total = (size_t)NT * KB * 256;
@@ -670,38 +1018,31 @@ int w4a16_repack(const void* qweight, const void* scales, const void* qzeros, vo
 int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* packed_sz,
                               const void* bias, void* out, int M, int K, int N, int G, int mt,
                               int t, int waves, void* stream) {
-  if (!x || !packed_w || !packed_sz || !out) return W4A16_E_NULL;
-  if (M <= 0) return W4A16_E_SHAPE;
-  const int rc = check_common(K, N, G);
-  if (rc) return rc;
-  if (K % 32) return W4A16_E_SHAPE;
-  if ((long long)M * N >= (1LL << 31) || (long long)M * K >= (1LL << 31)) return W4A16_E_TOO_LARGE;
-  if (misaligned(x) || misaligned(packed_w) || misaligned(packed_sz)) return W4A16_E_ALIGN;
-  if (reinterpret_cast<uintptr_t>(out) & 7u) return W4A16_E_ALIGN;
-  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return W4A16_E_ALIGN;
-  clear_stale_error();
   GemmArgs a;
-  a.x = (const f16*)x;
-  a.pw = (const u32x4*)packed_w;
-  a.psz = (const uint32_t*)packed_sz;
-  a.bias = (const f16*)bias;
-  a.out = (f16*)out;
-  a.M = M;
-  a.K = K;
-  a.N = N;
-  a.G = G;
-  a.NT = ceil_div(N, 16);
-  a.KB = ceil_div(K, 128);
-  a.NG = K / G;
+  const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
+  if (rc) return rc;
+  clear_stale_error();
   return dispatch_packed(a, mt, t, waves, static_cast<hipStream_t>(stream));
+}
+
+int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                                    const void* bias, void* out, int M, int K, int N, int G, int mt,
+                                    int t, int nw, int kw, void* stream) {
+  GemmArgs a;
+  const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
+  if (rc) return rc;
+  clear_stale_error();
+  return dispatch_tiled(a, mt, t, nw, kw, static_cast<hipStream_t>(stream));
 }
 
 int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
                           const void* bias, void* out, int M, int K, int N, int G, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0) return W4A16_E_SHAPE;
-  int mt, t, waves;
-  choose_cfg(M, K, N, &mt, &t, &waves);
-  return w4a16_gemm_packed_f16_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, mt, t, waves,
+  const Choice c = choose_cfg(M, K, N);
+  if (c.tiled)
+    return w4a16_gemm_packed_f16_tiled_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t,
+                                           c.a, c.b, stream);
+  return w4a16_gemm_packed_f16_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t, c.a,
                                    stream);
 }
 
@@ -711,7 +1052,7 @@ int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, voi
   const int rc = check_common(K, N, G);
   if (rc) return rc;
   clear_stale_error();
-  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128), NG = K / G;
+  const int NT = ceil_div(N, 16), KB = padded_kblocks(K), NG = K / G;
   const size_t total = (size_t)NT * KB * 256;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(dequant_packed_kernel, dim3(blocks), dim3(256), 0,
