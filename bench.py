@@ -295,13 +295,14 @@ def main():
     n_local = N // p
     flops_launch = 2.0 * M * K * n_local
     out["roofline"] = {
-        "kernel": "gemm_packed_kernel (M=128)",
+        "kernel": "gemm_tiled_kernel<4,3,2,4> (the M=128 launch w4a16_gemm_packed_f16 makes)",
         "bound": "mfma",
         "achieved": flops_launch / col_us * 1e-6,
         "peak": PEAK_F16_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flops_launch / col_us * 1e-6 / PEAK_F16_TFLOPS,
         "traffic": traffic.get("m128_hbm_bytes_per_launch") if p == 1 else None,
+        "traffic_source": traffic.get("source") if p == 1 else None,
         "algorithmic_bytes": algorithmic_bytes(M, K, n_local, G),
         "launch_us": col_us,
     }
@@ -319,7 +320,7 @@ def main():
             out["sweep"] = sweep
             m1 = sweep["1"]
             out["roofline_m1"] = {
-                "kernel": "gemm_packed_kernel (M=1)",
+                "kernel": "gemm_packed_kernel<1,3,16> (the M=1 launch w4a16_gemm_packed_f16 makes)",
                 "bound": "hbm",
                 "achieved": m1["GBps"],
                 "peak": PEAK_HBM_GBPS,

@@ -1,0 +1,80 @@
+"""Condenses rocprofv3 output (gpurun_out/<tag>_trace, _pmc_fetch, _pmc_write) into profiles/.
+
+usage: python scripts/summarize_profile.py r1
+Writes profiles/<tag>_kernel_stats.csv (per-kernel durations of the `--kernel-trace --stats` run),
+profiles/<tag>_traffic.json and profiles/traffic.json (HBM bytes per launch of the GEMM kernels,
+from the separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes).
+
+Counter conventions (MI355X): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a
+wide coalesced streaming read (16 B per lane, which is what these kernels issue) at exactly half
+its bytes, so the read side is doubled; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+out_dir = os.path.join(ROOT, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"(gemm_\w+_kernel<[^>]*>|dequant_\w+_kernel|repack_\w+_kernel)", name)
+    if m:
+        return m.group(1)
+    name = re.sub(r"\(.*", "", name)
+    return name[:80]
+
+
+def one(pattern):
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    if not files:
+        raise SystemExit(f"missing {pattern}")
+    return files[0]
+
+
+rows = list(csv.DictReader(open(one(f"{tag}_trace/*/*kernel_stats.csv"))))
+with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "calls", "avg_ns", "min_ns", "max_ns", "stddev_ns", "pct_of_gpu_time"])
+    for r in rows[:20]:
+        w.writerow([short(r["Name"]), r["Calls"], f"{float(r['AverageNs']):.0f}", r["MinNs"], r["MaxNs"],
+                    f"{float(r['StdDev']):.0f}", r["Percentage"]])
+
+
+def per_kernel(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        if not k.startswith("gemm_"):
+            continue
+        acc.setdefault(k, []).append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+fetch = per_kernel(one(f"{tag}_pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+write = per_kernel(one(f"{tag}_pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
+traffic = {"_note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes; "
+                    "FETCH_SIZE doubled per the gfx950 half-count of 16-byte-per-lane streaming reads",
+           "kernels": {}}
+for k in sorted(fetch):
+    f_kib, n = fetch[k]
+    w_kib = write.get(k, (0.0, 0))[0]
+    traffic["kernels"][k] = {"launches": n, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+                             "hbm_bytes_per_launch": (2 * f_kib + w_kib) * 1024}
+# the two launches bench.py reports rooflines for
+for key, pat in (("m128_hbm_bytes_per_launch", r"gemm_tiled_kernel<4, 3, 2, 4"), ("m1_hbm_bytes_per_launch", r"gemm_packed_kernel<1, 3, 16")):
+    for k, v in traffic["kernels"].items():
+        if re.match(pat, k):
+            traffic[key] = v["hbm_bytes_per_launch"]
+traffic["source"] = f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on bench.py)"
+for name in (f"{tag}_traffic.json", "traffic.json"):
+    with open(os.path.join(out_dir, name), "w") as f:
+        json.dump(traffic, f, indent=1)
+print(json.dumps(traffic, indent=1))
