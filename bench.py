@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline_m1    the M = 1 decode launch of the same layer (HBM-bound), N = 1 only,
   sweep          per-M kernel times of the whole M sweep, N = 1 only,
   cpu_baseline   torch.matmul(x, dequant(W)) with the oracle's dequantiser on the host cores, N = 1 only,
+  decode         Llama-2-7B-AWQ-shaped greedy decode tokens/s (benchmarks/llama_decode.py), N = 1 only,
   tp             column-/row-parallel halves of the step timed separately.
 """
 from __future__ import annotations
@@ -144,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the Llama-2-7B-shaped decode harness")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
     args = ap.parse_args()
 
@@ -336,6 +338,12 @@ def main():
             out["context"] = {"dense_fp16_matmul_m128_us": us, "dense_fp16_matmul_m128_tflops": 2.0 * M * K * N / us * 1e-6}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, K, N, G)
+        if not args.no_decode:
+            # second half of the headline metric: Llama-2-7B-AWQ-shaped greedy decode, tokens/s (TP=1)
+            del col, row
+            torch.cuda.empty_cache()
+            from benchmarks.llama_decode import run as decode_run
+            out["decode"] = decode_run("7b", (1, 8, 64), device=device)
 
     if rank == 0:
         print(json.dumps(out))

@@ -1,0 +1,228 @@
+"""Model-level measurement harness: greedy decode of a Llama-2-shaped AWQ model whose linear layers
+are this package's drop-in layers (`vllm_quick_amd.layers.linear` + `AWQLinearMethod`).
+
+This is a measurement stand-in for the reference's engine (scheduler, paged attention, sampler are out
+of scope): the non-GEMM pieces are stock PyTorch ops over a contiguous KV cache (RMSNorm, RoPE,
+`scaled_dot_product_attention`, SiLU-and-mul, fp16 lm_head + argmax), weights are synthetic and
+seeded (no checkpoint can be fetched), and one decode step per batch size is captured in a HIP graph
+the way the reference captures its decode batches (vllm/worker/model_runner.py:658-737).
+Layer order follows vllm/model_executor/models/llama.py:53-80 (MLP), :119-159 (attention), :197-223
+(decoder layer).  tokens/s = batch size / median step time (decode-only variant of
+benchmarks/benchmark_latency.py:59-65).
+
+    python benchmarks/llama_decode.py [--model 7b|70b] [--bs 1,2,4,8,16,32,64] [--layers N]
+    torchrun --nproc-per-node 8 benchmarks/llama_decode.py --model 70b      # tensor parallel
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vllm_quick_amd._C import ops  # noqa: E402,F401
+from vllm_quick_amd.layers.linear import (MergedColumnParallelLinear, QKVParallelLinear,  # noqa: E402
+                                          RowParallelLinear)
+from vllm_quick_amd.layers.quantization import AWQConfig  # noqa: E402
+from vllm_quick_amd.parallel_utils import parallel_state as ps  # noqa: E402
+
+SHAPES = {
+    # hidden, intermediate, heads, kv_heads, layers, vocab
+    "7b": dict(hidden=4096, inter=11008, heads=32, kv_heads=32, layers=32, vocab=32000),
+    "70b": dict(hidden=8192, inter=28672, heads=64, kv_heads=8, layers=80, vocab=32000),
+}
+
+
+def fill_awq(layer, gen, device):
+    """Seeded synthetic AWQ tensors: uniform bit patterns, scales U(1e-3, 2e-2) (the reference's
+    dummy loader leaves the int tensors uninitialised, weight_utils.py:286-300)."""
+    for name in ("qweight", "qzeros"):
+        p = getattr(layer, name)
+        p.data = torch.randint(-2**31, 2**31 - 1, p.shape, generator=gen, device=device, dtype=torch.int64).to(
+            torch.int32)
+    s = layer.scales
+    s.data = (torch.rand(s.shape, generator=gen, device=device) * (2e-2 - 1e-3) + 1e-3).half() * 0.1
+
+
+class DecoderLayer(torch.nn.Module):
+
+    def __init__(self, cfg, method, max_bs, max_len, device):
+        super().__init__()
+        h, heads, kvh = cfg["hidden"], cfg["heads"], cfg["kv_heads"]
+        tp = ps.get_tensor_model_parallel_world_size()
+        self.head_dim = h // heads
+        self.n_heads = heads // tp
+        self.n_kv = max(1, kvh // tp)
+        self.qkv_proj = QKVParallelLinear(h, self.head_dim, heads, kvh, bias=False, params_dtype=torch.float16,
+                                          linear_method=method)
+        self.o_proj = RowParallelLinear(h, h, bias=False, params_dtype=torch.float16, linear_method=method)
+        self.gate_up_proj = MergedColumnParallelLinear(h, [cfg["inter"]] * 2, bias=False,
+                                                       params_dtype=torch.float16, linear_method=method)
+        self.down_proj = RowParallelLinear(cfg["inter"], h, bias=False, params_dtype=torch.float16,
+                                           linear_method=method)
+        self.ln1 = torch.ones(h, dtype=torch.float16, device=device)
+        self.ln2 = torch.ones(h, dtype=torch.float16, device=device)
+        self.k_cache = torch.zeros(max_bs, self.n_kv, max_len, self.head_dim, dtype=torch.float16, device=device)
+        self.v_cache = torch.zeros_like(self.k_cache)
+
+    @staticmethod
+    def rms(x, w):
+        v = x.float()
+        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).half() * w
+
+    def forward(self, x, pos, cos, sin, ctx_len):
+        bs = x.shape[0]
+        hdn = self.rms(x, self.ln1)
+        qkv, _ = self.qkv_proj(hdn)
+        q, k, v = qkv.split([self.n_heads * self.head_dim, self.n_kv * self.head_dim, self.n_kv * self.head_dim], -1)
+        q = q.view(bs, self.n_heads, 1, self.head_dim)
+        k = k.view(bs, self.n_kv, 1, self.head_dim)
+        v = v.view(bs, self.n_kv, 1, self.head_dim)
+
+        def rope(t):
+            t1, t2 = t[..., :self.head_dim // 2], t[..., self.head_dim // 2:]
+            return torch.cat([t1 * cos - t2 * sin, t2 * cos + t1 * sin], -1)
+
+        q, k = rope(q), rope(k)
+        self.k_cache[:bs, :, pos:pos + 1] = k
+        self.v_cache[:bs, :, pos:pos + 1] = v
+        kk, vv = self.k_cache[:bs, :, :ctx_len], self.v_cache[:bs, :, :ctx_len]
+        if self.n_kv != self.n_heads:
+            rep = self.n_heads // self.n_kv
+            kk, vv = kk.repeat_interleave(rep, 1), vv.repeat_interleave(rep, 1)
+        att = F.scaled_dot_product_attention(q, kk, vv)
+        o, _ = self.o_proj(att.reshape(bs, -1))
+        x = x + o
+        hdn = self.rms(x, self.ln2)
+        gu, _ = self.gate_up_proj(hdn)
+        g, u = gu.chunk(2, -1)
+        d, _ = self.down_proj(F.silu(g) * u)
+        return x + d
+
+    def linears_only(self, x):
+        """The four W4A16 GEMMs of the layer with no other work (the hot path's share of a step)."""
+        a, _ = self.qkv_proj(x)
+        b, _ = self.o_proj(a[:, :self.o_proj.input_size_per_partition].contiguous())
+        c, _ = self.gate_up_proj(b)
+        d, _ = self.down_proj(c[:, :self.down_proj.input_size_per_partition].contiguous())
+        return d
+
+
+class Model(torch.nn.Module):
+
+    def __init__(self, cfg, n_layers, max_bs, max_len, device, seed=0):
+        super().__init__()
+        method = AWQConfig(4, 128, True).get_linear_method()
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.layers = torch.nn.ModuleList()
+        for _ in range(n_layers):
+            layer = DecoderLayer(cfg, method, max_bs, max_len, device).to(device)
+            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+                fill_awq(lin, gen, device)
+            self.layers.append(layer)
+        h = cfg["hidden"]
+        self.embed = (torch.randn(cfg["vocab"], h, generator=gen, device=device) * 0.05).half()
+        self.lm_head = (torch.randn(h, cfg["vocab"], generator=gen, device=device) * 0.02).half()
+        self.norm = torch.ones(h, dtype=torch.float16, device=device)
+        hd = h // cfg["heads"]
+        inv = 1.0 / (10000**(torch.arange(0, hd, 2, device=device).float() / hd))
+        t = torch.arange(max_len, device=device).float()
+        fr = torch.outer(t, inv)
+        self.cos, self.sin = fr.cos().half(), fr.sin().half()
+
+    def step(self, tokens, pos, ctx_len):
+        x = self.embed[tokens]
+        cos, sin = self.cos[pos], self.sin[pos]
+        for layer in self.layers:
+            x = layer(x, pos, cos, sin, ctx_len)
+        x = DecoderLayer.rms(x, self.norm)
+        return torch.argmax(x @ self.lm_head, -1)
+
+    def linears_only(self, x):
+        for layer in self.layers:
+            x = layer.linears_only(x)
+        return x
+
+
+def time_graph(fn, stream, reps=20):
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            fn()  # warm-up: repacks every layer's weights
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            fn()
+        g.replay()
+        stream.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            g.replay()
+            e1.record(stream)
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None):
+    cfg = SHAPES[model_name]
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    n_layers = n_layers or cfg["layers"]
+    with torch.inference_mode():
+        model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device)
+        stream = torch.cuda.Stream(device=device)
+        res = {}
+        for bs in batch_sizes:
+            tokens = torch.randint(0, cfg["vocab"], (bs, ), device=device)
+            ms = time_graph(lambda: model.step(tokens, ctx_len, ctx_len + 1), stream)
+            xin = (torch.randn(bs, cfg["hidden"], device=device) * 0.25).half()
+            ms_lin = time_graph(lambda: model.linears_only(xin), stream)
+            scale = cfg["layers"] / n_layers  # extrapolate a reduced-depth run to the full model
+            res[str(bs)] = {
+                "ms_per_step": ms * scale,
+                "tokens_per_s": bs / (ms * scale * 1e-3),
+                "w4a16_gemm_ms": ms_lin * scale,
+                "w4a16_share": ms_lin / ms,
+            }
+    return {"model": f"llama-2-{model_name}-awq-shaped (synthetic weights, g128)", "layers_run": n_layers,
+            "layers_model": cfg["layers"], "context": ctx_len, "tp": ps.get_tensor_model_parallel_world_size(),
+            "by_batch": res}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="7b", choices=sorted(SHAPES))
+    ap.add_argument("--bs", default="1,2,4,8,16,32,64")
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--ctx", type=int, default=128)
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ps.initialize_model_parallel(world)
+    t0 = time.time()
+    out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx)
+    out["wall_s"] = time.time() - t0
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,10 @@ class FakeOps:
     def stream_is_capturing(self):
         return False
 
+    @staticmethod
+    def tensor_version(t):
+        return t._version
+
     def awq_repack(self, qweight, scales, qzeros):
         self.trace.append(["repack"])
         return (qweight, scales, qzeros)

@@ -183,17 +183,26 @@ def awq_gemm_stock(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors
 # reference signature).  An entry is reused only for the very same tensor
 # objects at the same version counters, so in-place weight loading, freed and
 # re-used addresses and fresh views all miss and re-pack.
+def tensor_version(t: torch.Tensor) -> int:
+    """In-place-write counter of a tensor; inference-mode tensors keep none (they cannot be written in place
+    outside inference mode anyway), so those report 0."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 class _CacheEntry:
     __slots__ = ("refs", "versions", "packed")
 
     def __init__(self, tensors, packed):
         self.refs = tuple(weakref.ref(t) for t in tensors)
-        self.versions = tuple(t._version for t in tensors)
+        self.versions = tuple(tensor_version(t) for t in tensors)
         self.packed = packed
 
     def matches(self, tensors) -> bool:
         return all(r() is t for r, t in zip(self.refs, tensors)) and \
-            self.versions == tuple(t._version for t in tensors)
+            self.versions == tuple(tensor_version(t) for t in tensors)
 
 
 _repack_cache: Dict[Tuple, _CacheEntry] = {}

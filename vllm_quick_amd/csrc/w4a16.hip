@@ -29,6 +29,11 @@
 
 #include "../../include/w4a16.h"
 
+// Compile-time ablation switches for kernel experiments (scripts/); 0 in every shipped build.
+#ifndef W4A16_DBG
+#define W4A16_DBG 0
+#endif
+
 namespace {
 
 typedef _Float16 f16;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const f16x8 af = dequant_word(b.q[t][j], c[t], dqc);
+        const f16x8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(f16x8, b.q[t]) : dequant_word(b.q[t][j], c[t], dqc);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if constexpr (XPRE)
@@ -401,9 +406,6 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
     uint32_t sz[T][NSZ];
     u32x4 q[T];
   };
-#ifndef W4A16_DBG
-#define W4A16_DBG 0
-#endif
   auto load_w = [&](int kb, WBlock& b) {
     if ((W4A16_DBG & 2) && kb != kg) return;
     const int kbe = min(kb, a.KBS - 1);

@@ -111,7 +111,7 @@ class AWQLinearMethod(LinearMethodBase):
     def _packed(weights: Dict[str, Any]) -> Optional[ops.PackedAWQ]:
         """The layer's MFMA-ordered weights, (re)built when the stock tensors changed."""
         stock = (weights["qweight"], weights["scales"], weights["qzeros"])
-        stamp = tuple((t.data_ptr(), t._version) for t in stock)
+        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for t in stock)
         state = weights.get(_PACKED_KEY)
         if state is not None and state[0] == stamp:
             return state[1]
