@@ -345,6 +345,19 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
 // Load order per block iteration: next block's x share, then the weights two blocks ahead.
 // Vector-memory returns are counted in order, so this gives the L2-resident x one block and
 // the HBM weight stream two blocks of cover.
+#ifdef W4A16_STAMPS
+// Diagnostic build only: per-wave cycle stamps of the tiled kernel (never compiled into the
+// shipped library).  32 x 64-bit slots per wave.
+__device__ unsigned long long g_stamps[4096 * 32];
+#define STAMP(slot)                                                                      \
+  do {                                                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+    if (lane == 0) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (slot)] = t_;         \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 template <int MT, int T, int NW, int KW, int SZS>
 __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs a, int n_slices,
                                                                    int m_blocks) {
@@ -353,7 +366,6 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   constexpr int ROWS = MT * 16;
   constexpr int SLAB = ROWS * 256;                       // bytes: ROWS x 128 k of fp16
   constexpr int XLOADS = (ROWS / 4 + NW - 1) / NW;       // 16-byte loads per lane per slab share
-  static_assert(ROWS % (4 * NW) == 0, "each wave of a K-group loads whole 4-row pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int lane = threadIdx.x & 63;
@@ -361,6 +373,10 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   const int kg = w / NW, nw = w % NW;
   const int n16 = lane & 15;
   const int kq = lane >> 4;
+  STAMP(0);
+#ifdef W4A16_STAMPS
+  unsigned long long t_work = 0, t_bar = 0;
+#endif
 
   // Workgroups that share an XCD's L2 are those whose ids are equal mod 8.  Give the m_blocks
   // row-blocks of one column slice ids 8 apart, so their weight reads meet in one L2.
@@ -385,7 +401,10 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   int xdst[XLOADS];
 #pragma unroll
   for (int p = 0; p < XLOADS; ++p) {
-    const int row = (nw * XLOADS + p) * 4 + kq;
+    // (when NW does not divide the piece count the last wave repeats the last piece: same data
+    // to the same place)
+    const int piece = nw * XLOADS + p;
+    const int row = ((ROWS / 4) % NW != 0 ? min(piece, ROWS / 4 - 1) : piece) * 4 + kq;
     const int grow = min(m0 + row, a.M - 1);
     xsrc[p] = a.x + (size_t)grow * a.K + n16 * 8;
     xdst[p] = kg * SLAB + row * 256 + ((n16 ^ (row & 15)) << 4);
@@ -408,7 +427,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   };
   auto load_w = [&](int kb, WBlock& b) {
     if ((W4A16_DBG & 2) && kb != kg) return;
-    const int kbe = min(kb, a.KBS - 1);
+    const int kbe = (W4A16_DBG & 128) ? kg : min(kb, a.KBS - 1);
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -434,35 +453,25 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
     for (int p = 0; p < XLOADS; ++p)
       *reinterpret_cast<u32x4*>(smem_raw + buf * (KW * SLAB) + xdst[p]) = xr[p];
   };
-  auto compute = [&](int buf, const WBlock& b) {
-    SZ c[T];
+  // k-steps [j0, j1) of a block; `c` carries the expanded scale/zero constants across calls.
+  auto compute = [&](int buf, const WBlock& b, SZ (&c)[T], int j0, int j1) {
     const unsigned char* base = smem_raw + buf * (KW * SLAB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = j0; j < j1; ++j) {
       f16x8 xf[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if ((W4A16_DBG & 16) && j > 0) {
-          xf[mt] = __builtin_bit_cast(f16x8, b.q[0]);
-          continue;
-        }
+      for (int mt = 0; mt < MT; ++mt)
         xf[mt] = *reinterpret_cast<const f16x8*>(base + xfrag[mt] + (((4 * j + kq) ^ n16) << 4));
-      }
       if (j % SZS == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) c[t] = expand_sz(b.sz[t][j / SZS]);
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const f16x8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(f16x8, b.q[t]) : dequant_word(b.q[t][j], c[t], dqc);
+        const f16x8 af = dequant_word(b.q[t][j], c[t], dqc);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (W4A16_DBG & 4) {
-            acc[t][mt][0] += (float)af[mt & 7] * (float)xf[mt][j];
-            continue;
-          }
+        for (int mt = 0; mt < MT; ++mt)
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
-        }
       }
     }
   };
@@ -475,20 +484,52 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   const int iters = (W4A16_DBG & 32) ? 0 : a.KBS / KW;
   WBlock w0, w1, w2;
   u32x4 xr[XLOADS];
+  // Order of the loads matters more than their distance: a CU's vector-memory returns come back
+  // in issue order across all its waves, so an L2-resident x load issued behind an HBM weight
+  // load waits for HBM.  Every wave therefore issues its x share first (all waves leave the
+  // barrier together), and the weight loads follow one k-step later, behind every
+  // wave's x loads: the weights then have until the end of the NEXT phase to land before they
+  // hold anything up.
   auto phase = [&](int i, const WBlock& cur, WBlock& ahead) {
     const int kb = kg + i * KW;
+    SZ c[T];
+#ifdef W4A16_STAMPS
+    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
     load_xshare(kb + KW, xr);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(i & 1, cur, c, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     load_w(kb + 2 * KW, ahead);
     __builtin_amdgcn_sched_barrier(0);
-    compute(i & 1, cur);
+    compute(i & 1, cur, c, 1, 4);
     store_xshare((i + 1) & 1, xr);
+#ifdef W4A16_STAMPS
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS stores done, what the barrier needs anyway
+    const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef W4A16_STAMPS
+    const unsigned long long tc = __builtin_amdgcn_s_memtime();
+    t_work += tb - ta;
+    t_bar += tc - tb;
+    if (lane == 0 && i < 8) {
+      g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 8 + 2 * i] = tb - ta;
+      g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 9 + 2 * i] = tc - tb;
+    }
+#endif
   };
+  // Prologue: only what the first block needs stands between launch and the first MFMA; the
+  // second block's weights are requested once the first slab is on its way into LDS.
   load_xshare(kg, xr);
   load_w(kg, w0);
-  load_w(kg + KW, w1);
+  __builtin_amdgcn_sched_barrier(0);
   store_xshare(0, xr);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(kg + KW, w1);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  STAMP(1);
   int it = 0;
   for (; it + 3 <= iters; it += 3) {
     phase(it, w0, w2);
@@ -504,6 +545,14 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   // now: the loop ended on a barrier) and store.
   constexpr int TM = T * MT;
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+  STAMP(2);
+#ifdef W4A16_STAMPS
+  if (lane == 0) {
+    g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 5] = t_work;
+    g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 6] = t_bar;
+    g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   if (W4A16_DBG & 64) {
     if (acc[0][0][0] == 123.f) a.out[0] = (f16)1.0f;
     return;
@@ -511,6 +560,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
 #pragma unroll
   for (int i = 0; i < TM; ++i) red[((kg * NW + nw) * TM + i) * 64 + lane] = acc[i / MT][i % MT];
   __syncthreads();
+  STAMP(3);
   for (int o = w; o < NW * TM; o += NWAVES) {
     const int onw = o / TM, i = o - onw * TM;
     f32x4 v = red[(onw * TM + i) * 64 + lane];
@@ -526,6 +576,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
       *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
     }
   }
+  STAMP(4);
 }
 
 // ---------------------------------------------------------------------------
@@ -822,7 +873,7 @@ int launch_tiled(const GemmArgs& a, hipStream_t s) {
 
 // (mt, t, nw, kw) of the LDS-staged kernel
 #define W4A16_FOR_EACH_TILED(X) \
-  X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
+  X(4, 2, 3, 4) X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
   X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4)
 
 int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s) {
@@ -936,6 +987,13 @@ const char* w4a16_strerror(int code) {
 int w4a16_last_hip_error(void) { return g_last_hip_error; }
 
 int w4a16_abi_version(void) { return W4A16_ABI_VERSION; }
+
+#ifdef W4A16_STAMPS
+// Diagnostic build only: copies the stamp buffer to host memory (synchronises).
+int w4a16_dbg_stamps(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 size_t w4a16_packed_weight_bytes(int K, int N) {
   if (K <= 0 || N <= 0) return 0;
