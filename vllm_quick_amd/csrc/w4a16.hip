@@ -440,13 +440,14 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
 #pragma unroll
     for (int t = 0; t < T; ++t) b.q[t] = wp[t][(size_t)kbe * 64];
   };
-  auto load_xshare = [&](int kb, u32x4 (&xr)[XLOADS]) {
+  // loads pieces [p0, p1) of this wave's share of block kb's slab
+  auto load_xshare = [&](int kb, u32x4 (&xr)[XLOADS], int p0, int p1) {
     // chunks past K (K % 128 != 0 or a block past the end) re-read k = 0: their weights are zero
     if ((W4A16_DBG & 1) && kb != kg) return;
     const int k = kb * 128 + n16 * 8;
     const int koff = (k < a.K) ? kb * 128 : -(n16 * 8);
 #pragma unroll
-    for (int p = 0; p < XLOADS; ++p) xr[p] = *reinterpret_cast<const u32x4*>(xsrc[p] + koff);
+    for (int p = p0; p < p1; ++p) xr[p] = *reinterpret_cast<const u32x4*>(xsrc[p] + koff);
   };
   auto store_xshare = [&](int buf, const u32x4 (&xr)[XLOADS]) {
 #pragma unroll
@@ -454,14 +455,15 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
       *reinterpret_cast<u32x4*>(smem_raw + buf * (KW * SLAB) + xdst[p]) = xr[p];
   };
   // k-steps [j0, j1) of a block; `c` carries the expanded scale/zero constants across calls.
-  auto compute = [&](int buf, const WBlock& b, SZ (&c)[T], int j0, int j1) {
+  auto compute = [&](int buf, const WBlock& b, SZ (&c)[T], f16x8 (&xf)[MT], int j0, int j1) {
     const unsigned char* base = smem_raw + buf * (KW * SLAB);
 #pragma unroll
     for (int j = j0; j < j1; ++j) {
-      f16x8 xf[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        if ((W4A16_DBG & 16) && j > 0) continue;  // ablation: no LDS fragment reads after k-step 0
         xf[mt] = *reinterpret_cast<const f16x8*>(base + xfrag[mt] + (((4 * j + kq) ^ n16) << 4));
+      }
       if (j % SZS == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) c[t] = expand_sz(b.sz[t][j / SZS]);
@@ -484,31 +486,43 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   const int iters = (W4A16_DBG & 32) ? 0 : a.KBS / KW;
   WBlock w0, w1, w2;
   u32x4 xr[XLOADS];
-  // Order of the loads matters more than their distance: a CU's vector-memory returns come back
-  // in issue order across all its waves, so an L2-resident x load issued behind an HBM weight
-  // load waits for HBM.  Every wave therefore issues its x share first (all waves leave the
-  // barrier together), and the weight loads follow one k-step later, behind every
-  // wave's x loads: the weights then have until the end of the NEXT phase to land before they
-  // hold anything up.
+  // A CU's vector-memory returns come back in issue order across all its waves, so an
+  // L2-resident x load issued behind an HBM weight load waits for HBM, and a burst of loads at
+  // the top of a phase keeps every wave in the issue queue instead of the matrix core.  The x
+  // share is therefore issued in three portions ahead of k-steps 0-2 (all waves leave the barrier
+  // together, so every wave's x loads precede every wave's weight loads), and the weight loads
+  // follow k-step 2: they have until the end of the NEXT phase to land before they hold
+  // anything up.
   auto phase = [&](int i, const WBlock& cur, WBlock& ahead) {
     const int kb = kg + i * KW;
     SZ c[T];
+    f16x8 xf[MT];
 #ifdef W4A16_STAMPS
     const unsigned long long ta = __builtin_amdgcn_s_memtime();
 #endif
-    load_xshare(kb + KW, xr);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(i & 1, cur, c, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(kb + 2 * KW, ahead);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(i & 1, cur, c, 1, 4);
-    store_xshare((i + 1) & 1, xr);
+    // cumulative x pieces issued before k-step j (3/8, 3/8, 2/8 of the share), and the k-step
+    // after which the weight loads follow
+    constexpr int xs[4] = {3 * XLOADS / 8, 3 * XLOADS / 4, XLOADS, XLOADS};
+    constexpr int wstep = 2;
+    int done = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      load_xshare(kb + KW, xr, done, xs[j]);
+      done = xs[j];
+      __builtin_amdgcn_sched_barrier(0);
+      compute(i & 1, cur, c, xf, j, j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == wstep) {
+        load_w(kb + 2 * KW, ahead);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(W4A16_DBG & 4)) store_xshare((i + 1) & 1, xr);  // ablation 4: no LDS stores
 #ifdef W4A16_STAMPS
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS stores done, what the barrier needs anyway
     const unsigned long long tb = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();
+    if (!(W4A16_DBG & 8)) __syncthreads();  // ablation 8: no barrier
 #ifdef W4A16_STAMPS
     const unsigned long long tc = __builtin_amdgcn_s_memtime();
     t_work += tb - ta;
@@ -521,7 +535,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   };
   // Prologue: only what the first block needs stands between launch and the first MFMA; the
   // second block's weights are requested once the first slab is on its way into LDS.
-  load_xshare(kg, xr);
+  load_xshare(kg, xr, 0, XLOADS);
   load_w(kg, w0);
   __builtin_amdgcn_sched_barrier(0);
   store_xshare(0, xr);
