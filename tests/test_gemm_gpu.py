@@ -332,15 +332,19 @@ def test_awq_linear_method_matches_reference_fixture(cuda):
     from vllm_quick_amd.layers.quantization import AWQConfig
     meta = json.load(open(os.path.join(GOLDEN, "awq_reference_python.json")))
     arrays = np.load(os.path.join(GOLDEN, "awq_reference_python.npz"))
-    method = AWQConfig(4, 128, True).get_linear_method()
+    from vllm_quick_amd.layers.quantization.awq import AWQLinearMethod
+    cfg = AWQConfig(4, 128, True)
     weights = {k: dev_t(arrays[f"apply/{k}"], cuda) for k in ("qweight", "scales", "qzeros")}
     bias = dev_t(arrays["apply/bias"], cuda)
-    for label, spec in meta["apply_weights"].items():
-        x = dev_t(arrays[f"apply/{label}/x"], cuda)
-        y = method.apply_weights(weights, x, bias if spec["bias"] else None)
-        assert list(y.shape) == spec["out_shape"] and y.dtype == torch.float16
-        want = arrays[f"apply/{label}/out"].astype(np.float32)
-        assert np.allclose(y.float().cpu().numpy(), want, rtol=RTOL, atol=2 * ATOL), label
+    # default switch point (fused kernel for every fixture) and the reference's (256 tokens:
+    # the m256 fixture then goes through dequantise + matmul)
+    for method in (cfg.get_linear_method(), AWQLinearMethod(cfg, fp16_matmul_threshold=256)):
+        for label, spec in meta["apply_weights"].items():
+            x = dev_t(arrays[f"apply/{label}/x"], cuda)
+            y = method.apply_weights(weights, x, bias if spec["bias"] else None)
+            assert list(y.shape) == spec["out_shape"] and y.dtype == torch.float16
+            want = arrays[f"apply/{label}/out"].astype(np.float32)
+            assert np.allclose(y.float().cpu().numpy(), want, rtol=RTOL, atol=2 * ATOL), label
     assert "w4a16_packed" in weights  # the private layout is kept beside the stock tensors
 
 

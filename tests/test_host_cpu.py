@@ -83,7 +83,9 @@ def test_create_weights(meta):
 def test_apply_weights_dispatch_and_values(meta, arrays, monkeypatch):
     fake = FakeOps()
     monkeypatch.setattr(awq_mod, "ops", fake)
-    method = AWQConfig(4, 128, True).get_linear_method()
+    # with the reference's switch point the operator choice must match its recorded trace
+    method = awq_mod.AWQLinearMethod(AWQConfig(4, 128, True),
+                                     fp16_matmul_threshold=awq_mod.AWQLinearMethod.REFERENCE_FP16_MATMUL_THRESHOLD)
     weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
     bias = torch.from_numpy(arrays["apply/bias"])
     for label, spec in meta["apply_weights"].items():
@@ -119,6 +121,24 @@ def test_threshold_none_always_uses_fused_kernel(arrays, monkeypatch):
     weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
     method.apply_weights(weights, torch.from_numpy(arrays["apply/m256/x"]))
     assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm"]
+
+
+def test_default_switch_point_is_the_measured_one(arrays, monkeypatch):
+    """By default the fused kernel serves every batch below 1024 tokens (it is the faster route
+    there on MI355X); from 1024 the dequantise + matmul route of awq.py:154-159 takes over."""
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = AWQConfig(4, 128, True).get_linear_method()
+    assert method.fp16_matmul_threshold == 1024
+    weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
+    x = torch.from_numpy(arrays["apply/m256/x"])
+    method.apply_weights(weights, x)
+    big = x.repeat(4, 1)
+    assert big.shape[0] == 1024
+    y = method.apply_weights(weights, big)
+    assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm", "awq_dequantize"]
+    want = arrays["apply/m256/out"].astype(np.float32)
+    assert np.allclose(y[:256].numpy().astype(np.float32), want, rtol=1e-2, atol=1e-3)
 
 
 # --------------------------------------------------------------------------

@@ -75,11 +75,19 @@ class AWQLinearMethod(LinearMethodBase):
     Args:
         quant_config: The AWQ quantization config.
         fp16_matmul_threshold: token count from which `apply_weights` dequantises the
-            weights and calls `torch.matmul`, as the reference does (256, awq.py:155).
-            `None` always uses the fused W4A16 kernel.
+            weights to HBM and calls `torch.matmul`, the reference's large-batch route
+            (awq.py:154-159).  The reference switches at 256 tokens, a heuristic tuned to its
+            CUDA kernel; on MI355X the fused kernel stays ahead of dequantise + hipBLASLt up to
+            about a thousand tokens on Llama-2 shapes (2.2x at 256, 1.4x at 512, level at 1024,
+            behind from 2048), so the default here is 1024.  Pass 256 for the reference's exact
+            operator choice, `None` to always use the fused kernel.
     """
 
-    def __init__(self, quant_config: AWQConfig, fp16_matmul_threshold: Optional[int] = 256):
+    REFERENCE_FP16_MATMUL_THRESHOLD = 256
+    DEFAULT_FP16_MATMUL_THRESHOLD = 1024
+
+    def __init__(self, quant_config: AWQConfig,
+                 fp16_matmul_threshold: Optional[int] = DEFAULT_FP16_MATMUL_THRESHOLD):
         self.quant_config = quant_config
         self.fp16_matmul_threshold = fp16_matmul_threshold
 
