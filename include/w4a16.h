@@ -134,6 +134,23 @@ int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const v
                                     int t, int nw, int kw, void* stream);
 
 /*
+ * `batch` independent GEMMs of one shape in a single launch: problem b computes
+ *   out + b * out_batch_stride  =  (x + b * x_batch_stride) @ W_b  (+ bias + b * N)
+ * with W_b at packed_w + b * w4a16_packed_weight_bytes(K, N) and packed_sz +
+ * b * w4a16_packed_sz_bytes(K, N, G): the buffers of the problems stand back to back.
+ * Strides are in fp16 elements; x_batch_stride == 0 gives every problem the same activations;
+ * x_batch_stride must be a multiple of 8, out_batch_stride a multiple of 4 and >= M * N.
+ * Replaces the per-expert loop of the reference's quantised Mixtral block, which runs every
+ * local expert's w1 / w3 / w2 AWQ GEMM on all tokens one launch at a time
+ * (vllm/model_executor/models/mixtral_quant.py:87-93, 145-157): 16 gate/up problems share the
+ * tokens (stride 0), the 8 down projections take one activation matrix each.
+ */
+int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const void* packed_w,
+                                  const void* packed_sz, const void* bias, void* out,
+                                  long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                  void* stream);
+
+/*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16
  * on the tensors the buffers were packed from).
  */

@@ -32,3 +32,18 @@ class FakeOps:
         self.trace.append(["awq_dequantize", list(qweight.shape), split_k, thx, thy])
         return torch.from_numpy(
             orc.dequantize(qweight.detach().numpy(), scales.detach().numpy(), qzeros.detach().numpy()))
+
+    def awq_repack_batch(self, kernels, scaling_factors, zeros):
+        self.trace.append(["repack_batch", len(kernels)])
+        return list(zip(kernels, scaling_factors, zeros))
+
+    def awq_gemm_packed_batched(self, x, packed, bias=None):
+        self.trace.append(["awq_gemm_batched", list(x.shape), len(packed)])
+        outs = []
+        for e, (qw, s, qz) in enumerate(packed):
+            xe = x if x.dim() == 2 else x[e]
+            y = torch.from_numpy(
+                orc.gemm_faithful(xe.contiguous().numpy(), qw.detach().numpy(), s.detach().numpy(),
+                                  qz.detach().numpy()))
+            outs.append(y if bias is None else y + bias[e])
+        return torch.stack(outs)

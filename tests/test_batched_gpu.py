@@ -1,0 +1,131 @@
+"""GPU parity of the batched W4A16 launch (w4a16_gemm_packed_f16_batched, called through the C ABI)
+and of the mixture-of-experts block built on it, against the CPU oracle.  Tolerance as for the single
+GEMM: rtol 1e-2 / atol 1e-3 against the reference-faithful oracle; the batched launch must also agree
+BIT FOR BIT with one single launch per problem (same kernel, same order of additions)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-2, 1e-3
+
+
+def dev_t(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from vllm_quick_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vllm_quick_amd._C import ops
+    return ops
+
+
+def make_problems(E, M, K, N, G, seed, shared):
+    ws = [orc.make_inputs(M, K, N, G, seed=seed + e) for e in range(E)]
+    xs = ws[0][0] if shared else np.stack([w[0] for w in ws])
+    return xs, [w[1:] for w in ws]
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 70])
+@pytest.mark.parametrize("shared", [True, False])
+def test_batched_through_c_abi(L, cuda, M, shared):
+    E, K, N, G = 3, 384, 208, 128
+    xs, ws = make_problems(E, M, K, N, G, 40, shared)
+    lib = L.lib
+    wb, sb = lib.w4a16_packed_weight_bytes(K, N), lib.w4a16_packed_sz_bytes(K, N, G)
+    pw = torch.empty((E, wb), dtype=torch.uint8, device=cuda)
+    ps = torch.empty((E, sb), dtype=torch.uint8, device=cuda)
+    stream = torch.cuda.current_stream().cuda_stream
+    for e, (qw, s, qz) in enumerate(ws):
+        tq, ts, tz = dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda)
+        L.check(lib.w4a16_repack(tq.data_ptr(), ts.data_ptr(), tz.data_ptr(), pw[e].data_ptr(), ps[e].data_ptr(),
+                                 K, N, G, stream), "repack")
+    bias = (np.random.default_rng(1).standard_normal((E, N)) * 0.1).astype(np.float16)
+    tb = dev_t(bias, cuda)
+    tx = dev_t(xs, cuda)
+    out = torch.full((E, M, N), float("nan"), dtype=torch.float16, device=cuda)
+    L.check(lib.w4a16_gemm_packed_f16_batched(tx.data_ptr(), 0 if shared else M * K, pw.data_ptr(), ps.data_ptr(),
+                                              tb.data_ptr(), out.data_ptr(), M * N, M, K, N, G, E, stream),
+            "batched")
+    single = torch.empty((E, M, N), dtype=torch.float16, device=cuda)
+    for e in range(E):
+        xe = tx if shared else tx[e]
+        L.check(lib.w4a16_gemm_packed_f16(xe.data_ptr(), pw[e].data_ptr(), ps[e].data_ptr(), tb[e].data_ptr(),
+                                          single[e].data_ptr(), M, K, N, G, stream), "single")
+    got = out.cpu().numpy()
+    for e, (qw, s, qz) in enumerate(ws):
+        xe = xs if shared else xs[e]
+        want = orc.gemm_faithful(xe, qw, s, qz).astype(np.float32) + bias[e].astype(np.float32)
+        assert np.allclose(got[e].astype(np.float32), want, rtol=RTOL, atol=2 * ATOL), (e, M, shared)
+    # the default launch shape may differ between batch sizes (more problems, fewer tiles each), and
+    # with it the order of the fp32 additions: agreement within one fp16 ulp of the larger result
+    a, b = got.astype(np.float32), single.cpu().numpy().astype(np.float32)
+    assert np.abs(a - b).max() <= 2.0**-10 * max(1.0, np.abs(b).max())
+
+
+def test_batched_argument_errors(L, cuda):
+    lib = L.lib
+    t = torch.zeros(4096, dtype=torch.uint8, device=cuda)
+    p = t.data_ptr()
+    assert lib.w4a16_gemm_packed_f16_batched(p, 0, p, p, None, p, 16, 1, 128, 16, 128, 0, None) == -5  # batch 0
+    assert lib.w4a16_gemm_packed_f16_batched(p, 4, p, p, None, p, 16, 1, 128, 16, 128, 2, None) == -5  # x stride % 8
+    assert lib.w4a16_gemm_packed_f16_batched(p, 0, p, p, None, p, 8, 1, 128, 16, 128, 2, None) == -5   # out stride < M*N
+    assert lib.w4a16_gemm_packed_f16_batched(p, 0, p, p, None, p, 16, 1, 128, 12, 128, 2, None) == -1  # N % 8
+    assert lib.w4a16_gemm_packed_f16_batched(None, 0, p, p, None, p, 16, 1, 128, 16, 128, 2, None) == -4
+
+
+def test_ops_batched_wrapper(ops, cuda):
+    E, M, K, N, G = 4, 5, 256, 96, 64
+    xs, ws = make_problems(E, M, K, N, G, 70, shared=False)
+    packed = ops.awq_repack_batch([dev_t(w[0], cuda) for w in ws], [dev_t(w[1], cuda) for w in ws],
+                                  [dev_t(w[2], cuda) for w in ws])
+    assert packed.batch == E and (packed.K, packed.N, packed.G) == (K, N, G)
+    y = ops.awq_gemm_packed_batched(dev_t(xs, cuda), packed)
+    assert y.shape == (E, M, N)
+    for e, (qw, s, qz) in enumerate(ws):
+        want = orc.gemm_faithful(xs[e], qw, s, qz).astype(np.float32)
+        assert np.allclose(y[e].float().cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+        # a problem of the batch is an ordinary packed weight
+        y1 = ops.awq_gemm_packed(dev_t(xs[e], cuda), packed[e])
+        assert np.allclose(y1.float().cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    with pytest.raises(ValueError):
+        ops.awq_gemm_packed_batched(dev_t(xs[:2], cuda), packed)
+    with pytest.raises(RuntimeError):
+        ops.awq_gemm_packed_batched(dev_t(xs, cuda).float(), packed)
+
+
+def test_mixtral_block_on_gpu(cuda):
+    """Three batched launches against the reference's per-expert loop (mixtral_quant.py:133-160),
+    restated on the oracle."""
+    from test_experts_cpu import fill, reference_block
+    from vllm_quick_amd.layers import experts as X
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    E, top_k, H, I = 4, 2, 128, 224
+    method = AWQConfig(4, 32, True).get_linear_method()
+    moe = X.MixtralMoE(E, top_k, H, I, linear_method=method, params_dtype=torch.float16)
+    ck, gate = fill(moe, seed=9)
+    moe = moe.to(cuda)
+    x = (np.random.default_rng(2).standard_normal((2, 4, H)) * 0.5).astype(np.float16)
+    with torch.inference_mode():
+        y = moe(dev_t(x, cuda))
+        moe.batched = False
+        y_loop = moe(dev_t(x, cuda))
+    want = reference_block(x.reshape(8, H), gate, ck, moe.expert_indicies, top_k).astype(np.float32)
+    # Two chained GEMMs with outputs of magnitude ~10: the fp16 roundings of the intermediate and of
+    # the reference's own slices are absolute errors proportional to that magnitude, so the absolute
+    # part of the tolerance is scaled by it (the 1e-3 of the single GEMM assumes |y| = O(1)).
+    scale = max(1.0, float(np.abs(want).max()))
+    for got in (y, y_loop):
+        assert got.shape == (2, 4, H)
+        g = got.reshape(8, H).float().cpu().numpy()
+        assert (np.abs(g - want) <= RTOL * np.abs(want) + ATOL * scale).all()
+    # the two routes run the same kernels on the same numbers up to the final fp32-vs-fp16 expert sum
+    assert (y.float() - y_loop.float()).abs().max().item() <= 2.0**-9 * scale

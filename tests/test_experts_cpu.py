@@ -1,0 +1,99 @@
+"""Host logic of the mixture-of-experts block without a GPU: the native operators are replaced by
+oracle-backed fakes (tests/_fakes.py), and the block's output is checked against a numpy
+restatement of the reference's loop (vllm/model_executor/models/mixtral_quant.py:133-160)."""
+import numpy as np
+import torch
+
+from oracle import awq_oracle as orc
+from _fakes import FakeOps
+from vllm_quick_amd.layers import experts as X
+from vllm_quick_amd.layers.quantization import AWQConfig
+from vllm_quick_amd.layers.quantization import awq as awq_mod
+
+
+def fill(moe, seed):
+    """Seeded AWQ tensors for every local expert and a dense router."""
+    rng = np.random.default_rng(seed)
+    ck = {}
+    for idx in moe.expert_indicies:
+        for j, name in enumerate(("w1", "w2", "w3")):
+            lin = getattr(moe.experts[idx], name)
+            K, N = lin.input_size, lin.output_size
+            _, qw, s, qz = orc.make_inputs(1, K, N, 32, seed=seed * 100 + idx * 3 + j)
+            s = (s.astype(np.float32) * 4).astype(np.float16)
+            for pname, arr in (("qweight", qw), ("scales", s), ("qzeros", qz)):
+                with torch.no_grad():
+                    getattr(lin, pname).copy_(torch.from_numpy(arr))
+            ck[(idx, name)] = (qw, s, qz)
+    gate = rng.standard_normal(moe.gate.weight.shape).astype(np.float16)
+    moe.gate.weight.data.copy_(torch.from_numpy(gate))
+    return ck, gate
+
+
+def reference_block(x, gate, ck, experts, top_k):
+    """mixtral_quant.py:137-157 restated with the oracle's GEMM: fp16 tensors, fp32 routing."""
+    logits = torch.from_numpy(x) @ torch.from_numpy(gate).t()
+    w = torch.softmax(logits, dim=1, dtype=torch.float)
+    w, sel = torch.topk(w, top_k, dim=-1)
+    w /= w.sum(dim=-1, keepdim=True)
+    final = None
+    for idx in experts:
+        ew = (w * (sel == idx)).sum(dim=-1, keepdim=True)
+        h1 = torch.from_numpy(orc.gemm_faithful(x, *ck[(idx, "w1")]))
+        h3 = torch.from_numpy(orc.gemm_faithful(x, *ck[(idx, "w3")]))
+        act = torch.nn.functional.silu(h1) * h3
+        cur = torch.from_numpy(orc.gemm_faithful(act.numpy(), *ck[(idx, "w2")])).mul_(ew)
+        final = cur if final is None else final.add_(cur)
+    return final.numpy()
+
+
+def make(monkeypatch, E=4, top_k=2, H=64, I=96):
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    monkeypatch.setattr(X, "ops", fake)
+    method = AWQConfig(4, 32, True).get_linear_method()
+    moe = X.MixtralMoE(E, top_k, H, I, linear_method=method, params_dtype=torch.float16)
+    return moe, fake
+
+
+def test_parameter_tree_matches_the_reference_names(monkeypatch):
+    moe, _ = make(monkeypatch)
+    names = {n for n, _ in moe.named_parameters()}
+    assert "gate.weight" in names
+    for idx in range(4):
+        for w in ("w1", "w2", "w3"):
+            for p in ("qweight", "qzeros", "scales"):
+                assert f"experts.{idx}.{w}.{p}" in names
+    assert moe.experts[0].w1.qweight.shape == (64, 96 // 8)
+    assert moe.experts[0].w2.qweight.shape == (96, 64 // 8)
+
+
+def test_batched_block_matches_reference_loop(monkeypatch):
+    moe, fake = make(monkeypatch)
+    ck, gate = fill(moe, seed=3)
+    x = (np.random.default_rng(5).standard_normal((2, 3, 64)) * 0.5).astype(np.float16)
+    y = moe(torch.from_numpy(x))
+    assert y.shape == (2, 3, 64) and y.dtype == torch.float16
+    calls = [t for t in fake.trace if t[0] == "awq_gemm_batched"]
+    # three launches in all: 2E gate/up problems on the shared tokens, E down projections
+    assert calls == [["awq_gemm_batched", [6, 64], 8], ["awq_gemm_batched", [4, 6, 96], 4]]
+    want = reference_block(x.reshape(6, 64), gate, ck, moe.expert_indicies, 2)
+    assert np.allclose(y.reshape(6, 64).numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=2e-3)
+    # the re-layout is cached until a weight is written again
+    moe(torch.from_numpy(x))
+    assert [t[0] for t in fake.trace].count("repack_batch") == 2
+    with torch.no_grad():
+        moe.experts[1].w2.qweight.add_(0)
+    moe(torch.from_numpy(x))
+    assert [t[0] for t in fake.trace].count("repack_batch") == 4
+
+
+def test_unbatched_fallback_is_the_reference_loop(monkeypatch):
+    moe, fake = make(monkeypatch)
+    ck, gate = fill(moe, seed=4)
+    moe.batched = False
+    x = (np.random.default_rng(6).standard_normal((1, 5, 64)) * 0.5).astype(np.float16)
+    y = moe(torch.from_numpy(x))
+    assert [t[0] for t in fake.trace if t[0].startswith("awq_gemm")] == ["awq_gemm"] * 12
+    want = reference_block(x.reshape(5, 64), gate, ck, moe.expert_indicies, 2)
+    assert np.allclose(y.reshape(5, 64).numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=2e-3)

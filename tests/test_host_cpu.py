@@ -241,3 +241,22 @@ def test_layer_conventions(monkeypatch):
                             linear_method=m128)
     with pytest.raises(AssertionError):
         L.set_weight_attrs(layer.qweight, {"input_dim": 1})
+
+
+def test_weight_loader_after_a_forward_invalidates_the_packed_copy(monkeypatch):
+    """Loaders write through `param.data`, which leaves the tensor's write counter alone; the layers'
+    loaders mark the parameter as written so the W4A16 method re-packs on the next call."""
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = AWQConfig(4, 32, True).get_linear_method()
+    layer = L.ColumnParallelLinear(64, 128, bias=False, params_dtype=torch.float16, linear_method=method)
+    first, second = ckpt(64, 128, 11), ckpt(64, 128, 12)
+    x = torch.from_numpy(orc.make_inputs(2, 64, 128, 32, seed=13)[0])
+    for ck in (first, second):
+        for n in ck:
+            p = getattr(layer, n)
+            p.weight_loader(p, torch.from_numpy(ck[n]))
+        out, _ = layer(x)
+        want = orc.gemm_faithful(x.numpy(), ck["qweight"], ck["scales"], ck["qzeros"])
+        assert np.allclose(out.detach().numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=1e-3)
+    assert [t[0] for t in fake.trace].count("repack") == 2

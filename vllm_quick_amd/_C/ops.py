@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import weakref
 from dataclasses import dataclass
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -157,6 +157,94 @@ def awq_gemm_packed(in_feats: torch.Tensor,
                                                packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M, packed.K,
                                                packed.N, packed.G, mt, t, waves, _stream())
         check(rc, "awq_gemm")
+    return out
+
+
+@dataclass
+class PackedAWQBatch:
+    """E same-shaped weight matrices in the private layout, back to back (the form
+    w4a16_gemm_packed_f16_batched reads): e.g. the experts of a quantised Mixtral block."""
+    packed_w: torch.Tensor  # uint8 [E, w4a16_packed_weight_bytes]
+    packed_sz: torch.Tensor  # uint8 [E, w4a16_packed_sz_bytes]
+    K: int
+    N: int
+    G: int
+
+    @property
+    def device(self) -> torch.device:
+        return self.packed_w.device
+
+    @property
+    def batch(self) -> int:
+        return self.packed_w.shape[0]
+
+    def __getitem__(self, e: int) -> PackedAWQ:
+        return PackedAWQ(self.packed_w[e], self.packed_sz[e], self.K, self.N, self.G)
+
+
+def awq_repack_batch(kernels, scaling_factors, zeros) -> PackedAWQBatch:
+    """Sequences (or stacked [E, ...] tensors) of same-shaped stock AWQ tensors -> PackedAWQBatch."""
+    E = len(kernels)
+    if E == 0 or len(scaling_factors) != E or len(zeros) != E:
+        raise ValueError("need the same, non-zero number of kernels, scaling_factors and zeros")
+    K, N, G = _geometry(kernels[0], scaling_factors[0], zeros[0])
+    wbytes = lib.w4a16_packed_weight_bytes(K, N)
+    sbytes = lib.w4a16_packed_sz_bytes(K, N, G)
+    if wbytes == 0 or sbytes == 0:
+        raise ValueError(f"cannot repack K={K} N={N} G={G}")
+    dev = kernels[0].device
+    with _on_device(dev):
+        pw = torch.empty((E, wbytes), dtype=torch.uint8, device=dev)
+        ps = torch.empty((E, sbytes), dtype=torch.uint8, device=dev)
+        for e in range(E):
+            if _geometry(kernels[e], scaling_factors[e], zeros[e]) != (K, N, G) or kernels[e].device != dev:
+                raise ValueError("all problems of a batch must have one shape and one device")
+            k, s, z = kernels[e].contiguous(), scaling_factors[e].contiguous(), zeros[e].contiguous()
+            check(
+                lib.w4a16_repack(k.data_ptr(), s.data_ptr(), z.data_ptr(), pw[e].data_ptr(), ps[e].data_ptr(), K, N,
+                                 G, _stream()), "awq_repack")
+    return PackedAWQBatch(pw, ps, K, N, G)
+
+
+def awq_gemm_packed_batched(in_feats: torch.Tensor,
+                            packed: PackedAWQBatch,
+                            bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One launch for E GEMMs of one shape: in_feats [M, K] (shared by all problems) or [E, M, K] fp16,
+    optional bias [E, N] -> [E, M, N] fp16.  Stands in for the reference's loop over experts
+    (mixtral_quant.py:145-157)."""
+    _require(in_feats, torch.float16, "in_feats")
+    E = packed.batch
+    if in_feats.dim() == 2:
+        shared = True
+    elif in_feats.dim() == 3 and in_feats.shape[0] == E:
+        shared = False
+    else:
+        raise ValueError(f"in_feats must be [M, {packed.K}] or [{E}, M, {packed.K}], got {tuple(in_feats.shape)}")
+    if in_feats.shape[-1] != packed.K:
+        raise ValueError(f"in_feats must be [..., {packed.K}], got {tuple(in_feats.shape)}")
+    if in_feats.device != packed.device:
+        raise RuntimeError("in_feats and the packed weights are on different devices")
+    x = in_feats.contiguous()
+    M = x.shape[-2]
+    bias_ptr = None
+    if bias is not None:
+        _require(bias, torch.float16, "bias")
+        if tuple(bias.shape) != (E, packed.N):
+            raise ValueError(f"bias must be [{E}, {packed.N}]")
+        bias = bias.contiguous()
+        bias_ptr = bias.data_ptr()
+    with _on_device(x.device):
+        out = torch.empty((E, M, packed.N), dtype=torch.float16, device=x.device)
+        if M == 0:
+            return out
+        if (M * packed.K) % 8 and not shared:
+            raise ValueError("M * K must be a multiple of 8 for per-problem activations")
+        if (M * packed.N) % 4:
+            raise ValueError("M * N must be a multiple of 4")
+        check(
+            lib.w4a16_gemm_packed_f16_batched(x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
+                                              packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * packed.N, M,
+                                              packed.K, packed.N, packed.G, E, _stream()), "awq_gemm_batched")
     return out
 
 

@@ -138,7 +138,22 @@ struct GemmArgs {
   int M, K, N, G;
   int NT, KB, NG;
   int KBS;  // 128-k blocks per column tile in the packed layout (KB rounded up to a multiple of 4)
+  // Batched launches (gridDim.z problems of one shape): element strides from one problem to the
+  // next; all zero for a single GEMM.  x_bs == 0 shares the activations between the problems.
+  long long x_bs, out_bs, pw_bs, psz_bs, bias_bs;
 };
+
+// The argument block of problem blockIdx.z of a batched launch (scalar arithmetic only).
+__device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
+  GemmArgs a = g;
+  const long long b = blockIdx.z;
+  a.x = g.x + b * g.x_bs;
+  a.pw = g.pw + b * g.pw_bs;
+  a.psz = g.psz + b * g.psz_bs;
+  a.bias = g.bias ? g.bias + b * g.bias_bs : nullptr;
+  a.out = g.out + b * g.out_bs;
+  return a;
+}
 
 // MT : 16-row tiles of the output per workgroup
 // T  : 16-column tiles per workgroup
@@ -146,7 +161,8 @@ struct GemmArgs {
 // SZS: k-steps (of 32) covered by one scale/zero word: 4 when G % 128 == 0,
 //      2 when G == 64, 1 for any other multiple of 32
 template <int MT, int T, int W, int SZS>
-__global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) {
+  const GemmArgs a = batch_slice(ga);
   constexpr int NSZ = 4 / SZS;  // scale/zero words per 128-k block and tile
   constexpr int TM = T * MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -359,8 +375,9 @@ __device__ unsigned long long g_stamps[4096 * 32];
 #endif
 
 template <int MT, int T, int NW, int KW, int SZS>
-__global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs a, int n_slices,
+__global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs ga, int n_slices,
                                                                    int m_blocks) {
+  const GemmArgs a = batch_slice(ga);
   constexpr int NWAVES = NW * KW;
   constexpr int NSZ = 4 / SZS;
   constexpr int ROWS = MT * 16;
@@ -805,7 +822,8 @@ int launched() {
 
 // Validates the arguments of the packed-layout GEMM entry points and fills the kernel argument block.
 int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* packed_sz, const void* bias,
-              void* out, int M, int K, int N, int G) {
+              void* out, int M, int K, int N, int G, int batch = 1, long long x_batch_stride = 0,
+              long long out_batch_stride = 0) {
   if (!x || !packed_w || !packed_sz || !out) return W4A16_E_NULL;
   if (M <= 0) return W4A16_E_SHAPE;
   const int rc = check_common(K, N, G);
@@ -828,13 +846,25 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   a->KB = ceil_div(K, 128);
   a->KBS = padded_kblocks(K);
   a->NG = K / G;
+  a->x_bs = a->out_bs = a->pw_bs = a->psz_bs = a->bias_bs = 0;
+  if (batch != 1) {
+    if (batch < 1 || batch > 65535) return W4A16_E_SHAPE;
+    // every problem's buffers must keep the alignment the kernels rely on
+    if (x_batch_stride < 0 || x_batch_stride % 8 || out_batch_stride < (long long)M * N || out_batch_stride % 4)
+      return W4A16_E_SHAPE;
+    a->x_bs = x_batch_stride;
+    a->out_bs = out_batch_stride;
+    a->pw_bs = (long long)a->NT * a->KBS * 64;   // u32x4 units: w4a16_packed_weight_bytes / 16
+    a->psz_bs = (long long)a->NT * a->NG * 16;   // uint32 units: w4a16_packed_sz_bytes / 4
+    a->bias_bs = N;
+  }
   return W4A16_OK;
 }
 
 template <int MT, int T, int W>
-int launch_packed(const GemmArgs& a, hipStream_t s) {
+int launch_packed(const GemmArgs& a, hipStream_t s, int batch) {
   const size_t lds = (size_t)reduce_lds_tiles(W, T * MT) * 1024;
-  const dim3 grid(ceil_div(a.NT, T), ceil_div(a.M, MT * 16));
+  const dim3 grid(ceil_div(a.NT, T), ceil_div(a.M, MT * 16), batch);
   const dim3 block(64 * W);
   void (*kern)(const GemmArgs) = nullptr;
   if (a.G % 128 == 0)
@@ -857,7 +887,7 @@ int launch_packed(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int MT, int T, int NW, int KW>
-int launch_tiled(const GemmArgs& a, hipStream_t s) {
+int launch_tiled(const GemmArgs& a, hipStream_t s, int batch) {
   constexpr int stage = 2 * KW * MT * 16 * 256;         // double-buffered slabs
   constexpr int reduce = NW * KW * T * MT * 1024;       // partial tiles
   constexpr int lds = stage > reduce ? stage : reduce;
@@ -881,7 +911,7 @@ int launch_tiled(const GemmArgs& a, hipStream_t s) {
       return W4A16_E_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW * KW), lds, s, a, n_slices, m_blocks);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW * KW), lds, s, a, n_slices, m_blocks);
   return launched();
 }
 
@@ -890,9 +920,9 @@ int launch_tiled(const GemmArgs& a, hipStream_t s) {
   X(4, 2, 3, 4) X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
   X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4)
 
-int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s) {
+int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1) {
 #define X(MT_, T_, NW_, KW_) \
-  if (mt == MT_ && t == T_ && nw == NW_ && kw == KW_) return launch_tiled<MT_, T_, NW_, KW_>(a, s);
+  if (mt == MT_ && t == T_ && nw == NW_ && kw == KW_) return launch_tiled<MT_, T_, NW_, KW_>(a, s, batch);
   W4A16_FOR_EACH_TILED(X)
 #undef X
   return W4A16_E_SHAPE;
@@ -912,9 +942,9 @@ int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t
   X(8, 1, 8)  X(8, 2, 8)  X(8, 3, 8)                                      \
   X(8, 1, 4)  X(8, 2, 4)  X(8, 3, 4)
 
-int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s) {
+int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1) {
 #define X(MT_, T_, W_) \
-  if (mt == MT_ && t == T_ && waves == W_) return launch_packed<MT_, T_, W_>(a, s);
+  if (mt == MT_ && t == T_ && waves == W_) return launch_packed<MT_, T_, W_>(a, s, batch);
   W4A16_FOR_EACH_CFG(X)
 #undef X
   return W4A16_E_SHAPE;
@@ -939,7 +969,7 @@ struct Choice {
   int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
 };
 
-Choice choose_cfg(int M, int K, int N) {
+Choice choose_cfg(int M, int K, int N, int batch = 1) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
@@ -947,7 +977,7 @@ Choice choose_cfg(int M, int K, int N) {
     const int MT = mtiles;
     int Wv = (MT == 1) ? 16 : 8;
     while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
-    int Tt = ceil_div(NT, cus);  // one workgroup per CU (registers and LDS admit no second one)
+    int Tt = ceil_div((long long)NT * batch, cus);  // one workgroup per CU (registers and LDS admit no second one)
     if (Tt < 1) Tt = 1;
     if (Tt == 5) Tt = 6;
     if (Tt == 7) Tt = 8;
@@ -965,7 +995,7 @@ Choice choose_cfg(int M, int K, int N) {
   for (const auto& c : cand) {
     const int mt = c[0], t = c[1], nw = c[2], kw = c[3];
     if (mtiles <= 4 && mt == 4 && mtiles <= 2) continue;
-    const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt);
+    const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt) * batch;
     const double rounds = (double)ceil_div(ctas, cus);
     double cost = rounds * mt * t * nw;               // matrix work per workgroup
     cost *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
@@ -1118,6 +1148,23 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
                                            c.a, c.b, stream);
   return w4a16_gemm_packed_f16_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t, c.a,
                                    stream);
+}
+
+int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const void* packed_w,
+                                  const void* packed_sz, const void* bias, void* out,
+                                  long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                  void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
+  GemmArgs a;
+  const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G, batch, x_batch_stride,
+                           out_batch_stride);
+  if (rc) return rc;
+  if ((long long)batch * out_batch_stride >= (1LL << 40)) return W4A16_E_TOO_LARGE;
+  clear_stale_error();
+  const Choice c = choose_cfg(M, K, N, batch);
+  const hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c.tiled) return dispatch_tiled(a, c.mt, c.t, c.a, c.b, s, batch);
+  return dispatch_packed(a, c.mt, c.t, c.a, s, batch);
 }
 
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,

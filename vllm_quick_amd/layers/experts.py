@@ -1,0 +1,140 @@
+"""Quantised mixture-of-experts block on batched W4A16 launches.
+
+Host-side mirror of `MixtralMLP` / `MixtralMoE` in the reference
+(vllm/model_executor/models/mixtral_quant.py:57-93, 96-160): same constructor arguments,
+the same parameter tree (`experts.<i>.w1|w2|w3.{qweight,qzeros,scales}`, `gate.weight`), the
+same routing arithmetic, experts split over the tensor-parallel ranks the same way with one
+all-reduce at the end.  What differs is how the local experts run.  The reference calls every
+local expert on all tokens, one AWQ GEMM launch at a time (3 launches per expert, :145-157);
+here the local experts' weights are kept back to back in the private layout and the block
+takes three launches in total:
+
+    [w1_0 .. w1_{E-1}, w3_0 .. w3_{E-1}]  x  tokens        2E problems, shared activations
+    silu(w1 out) * w3 out                                   elementwise (torch)
+    [w2_0 .. w2_{E-1}]                   x  per-expert act  E problems
+
+followed by the routing-weighted sum over experts.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .._C import ops
+from ..parallel_utils.communication_op import tensor_model_parallel_all_reduce
+from ..parallel_utils.parallel_state import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size)
+from .linear import LinearMethodBase, ReplicatedLinear
+from .quantization.awq import AWQLinearMethod
+
+
+class MixtralMLP(torch.nn.Module):
+    """One expert: w2(silu(w1 x) * w3 x) (mixtral_quant.py:57-93).  Used on its own it runs three
+    single launches through the layer's linear method, like the reference."""
+
+    def __init__(self, num_experts: int, hidden_size: int, intermediate_size: int,
+                 linear_method: Optional[LinearMethodBase] = None, params_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        self.num_experts = num_experts
+        self.ffn_dim = intermediate_size
+        self.hidden_dim = hidden_size
+        self.w1 = ReplicatedLinear(hidden_size, intermediate_size, bias=False, params_dtype=params_dtype,
+                                   linear_method=linear_method)
+        self.w2 = ReplicatedLinear(intermediate_size, hidden_size, bias=False, params_dtype=params_dtype,
+                                   linear_method=linear_method)
+        self.w3 = ReplicatedLinear(hidden_size, intermediate_size, bias=False, params_dtype=params_dtype,
+                                   linear_method=linear_method)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        w1_out, _ = self.w1(hidden_states)
+        w3_out, _ = self.w3(hidden_states)
+        out, _ = self.w2(F.silu(w1_out) * w3_out)
+        return out
+
+
+class MixtralMoE(torch.nn.Module):
+    """Router + this rank's experts (mixtral_quant.py:96-160).
+
+    Args mirror the reference's (`config.num_local_experts`, `num_experts_per_tok`, `hidden_size`,
+    `intermediate_size`) as plain integers, since no HF config class is needed for them.
+    """
+
+    def __init__(self, num_total_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
+                 linear_method: Optional[LinearMethodBase] = None, params_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        self.rank = get_tensor_model_parallel_rank()
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.num_total_experts = num_total_experts
+        self.top_k = top_k
+        if self.tp_size > num_total_experts:
+            raise ValueError(f"Tensor parallel size {self.tp_size} is greater than "
+                             f"the number of experts {num_total_experts}.")
+        # experts are split equally between ranks (mixtral_quant.py:113-118)
+        self.expert_indicies: List[int] = np.array_split(range(num_total_experts), self.tp_size)[self.rank].tolist()
+        if not self.expert_indicies:
+            raise ValueError(f"Rank {self.rank} has no experts assigned to it.")
+        self.experts = torch.nn.ModuleList([
+            MixtralMLP(num_total_experts, hidden_size, intermediate_size, linear_method, params_dtype)
+            if idx in self.expert_indicies else None for idx in range(num_total_experts)
+        ])
+        self.gate = ReplicatedLinear(hidden_size, num_total_experts, bias=False, params_dtype=params_dtype,
+                                     linear_method=None)
+        self.batched = isinstance(linear_method, AWQLinearMethod)
+        self._packed = None  # (stamp, w13 batch, w2 batch)
+
+    # ------------------------------------------------------------------
+    def _stock(self, names):
+        out = []
+        for name in names:
+            for idx in self.expert_indicies:
+                lin = getattr(self.experts[idx], name)
+                out.append((lin.qweight, lin.scales, lin.qzeros))
+        return out
+
+    def _batches(self):
+        """The local experts' weights back to back in the private layout, rebuilt when any stock
+        tensor was written since (weight loading)."""
+        w13, w2 = self._stock(("w1", "w3")), self._stock(("w2", ))
+        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for trio in w13 + w2 for t in trio)
+        if self._packed is not None and self._packed[0] == stamp:
+            return self._packed[1], self._packed[2]
+        if ops.stream_is_capturing():
+            return None  # no re-layout inside a graph capture
+        b13 = ops.awq_repack_batch(*[[trio[i] for trio in w13] for i in (0, 1, 2)])
+        b2 = ops.awq_repack_batch(*[[trio[i] for trio in w2] for i in (0, 1, 2)])
+        self._packed = (stamp, b13, b2)
+        return b13, b2
+
+    def routing(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """[tokens, local experts] fp32 weights: softmax, top-k, renormalise (mixtral_quant.py:137-150)."""
+        router_logits, _ = self.gate(hidden_states)
+        routing_weights = F.softmax(router_logits, dim=1, dtype=torch.float)
+        routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
+        routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
+        dense = torch.zeros_like(router_logits, dtype=torch.float).scatter_(1, selected_experts, routing_weights)
+        return dense[:, self.expert_indicies]
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        batch_size, sequence_length, hidden_dim = hidden_states.shape
+        hidden_states = hidden_states.view(-1, hidden_dim)
+        expert_weights = self.routing(hidden_states)  # [T, E_local]
+        batches = self._batches() if self.batched else None
+        if batches is None:
+            # the reference's loop (mixtral_quant.py:145-157)
+            final = None
+            for j, idx in enumerate(self.expert_indicies):
+                cur = self.experts[idx](hidden_states).mul_(expert_weights[:, j:j + 1])
+                final = cur if final is None else final.add_(cur)
+        else:
+            b13, b2 = batches
+            E = len(self.expert_indicies)
+            h13 = ops.awq_gemm_packed_batched(hidden_states, b13)  # [2E, T, I]
+            act = F.silu(h13[:E]) * h13[E:]
+            y = ops.awq_gemm_packed_batched(act, b2)  # [E, T, H]
+            # each expert's output is scaled in fp32 and rounded to fp16 as `.mul_` does; the sum
+            # over experts is taken in fp32 and rounded once
+            scaled = (y.float() * expert_weights.t().unsqueeze(-1)).to(y.dtype)
+            final = scaled.float().sum(0).to(y.dtype)
+        return tensor_model_parallel_all_reduce(final).view(batch_size, sequence_length, hidden_dim)

@@ -88,10 +88,27 @@ def _packed_units(param: torch.Tensor, dim: Optional[int], offset: int, size: in
     return offset, size
 
 
-def _copy_shard(dst: torch.Tensor, src: torch.Tensor) -> None:
+def _copy_shard(dst: torch.Tensor, src: torch.Tensor, owner: Optional[torch.Tensor] = None) -> None:
+    """Copy a checkpoint shard into (a slice of) a parameter's storage.
+
+    Loaders write through `param.data`, as the reference's do; such writes leave the parameter's
+    in-place-write counter alone, and linear methods that keep a derived copy of the weights (the
+    W4A16 method's MFMA-ordered layout) watch exactly that counter.  So the owner is marked as
+    written by hand.
+    """
     if dst.shape != src.shape:
         raise AssertionError(f"shard shape mismatch: parameter {tuple(dst.shape)} vs checkpoint {tuple(src.shape)}")
     dst.copy_(src)
+    if owner is not None:
+        mark_written(owner)
+
+
+def mark_written(param: torch.Tensor) -> None:
+    """Bump a tensor's in-place-write counter after a write that bypassed it (`param.data...`)."""
+    try:
+        torch._C._increment_version(param)
+    except (RuntimeError, AttributeError):  # inference tensors keep no counter
+        pass
 
 
 class _LinearBase(torch.nn.Module):
@@ -162,7 +179,7 @@ class ColumnParallelLinear(_LinearBase):
         if out_dim is not None:
             width = param.data.shape[out_dim]
             loaded_weight = loaded_weight.narrow(out_dim, get_tensor_model_parallel_rank() * width, width)
-        _copy_shard(param.data, loaded_weight)
+        _copy_shard(param.data, loaded_weight, param)
 
     def forward(self, input_: torch.Tensor):
         fused_bias = None if self.skip_bias_add else self.bias
@@ -193,7 +210,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         if loaded_shard_id is None:
             # The checkpoint stores the fused matrix: peel the sub-matrices off and load each.
             if out_dim is None:
-                _copy_shard(param.data, loaded_weight)
+                _copy_shard(param.data, loaded_weight, param)
                 return
             start = 0
             for idx, size in enumerate(self.output_sizes):
@@ -213,7 +230,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         elif not getattr(param, "ignore_warning", False):
             logger.warning("Loading a weight without `output_dim` attribute in MergedColumnParallelLinear, "
                            "assume the weight is the same for all partitions.")
-        _copy_shard(dst, loaded_weight)
+        _copy_shard(dst, loaded_weight, param)
 
 
 class QKVParallelLinear(ColumnParallelLinear):
@@ -247,7 +264,7 @@ class QKVParallelLinear(ColumnParallelLinear):
         out_dim = getattr(param, "output_dim", None)
         if loaded_shard_id is None:
             if out_dim is None:
-                _copy_shard(param.data, loaded_weight)
+                _copy_shard(param.data, loaded_weight, param)
                 return
             q_all = self.total_num_heads * self.head_size
             kv_all = self.total_num_kv_heads * self.head_size
@@ -267,7 +284,7 @@ class QKVParallelLinear(ColumnParallelLinear):
         elif not getattr(param, "ignore_warning", False):
             logger.warning("Loading a weight without `output_dim` attribute in QKVParallelLinear, "
                            "assume the weight is the same for all partitions.")
-        _copy_shard(dst, loaded_weight)
+        _copy_shard(dst, loaded_weight, param)
 
 
 class RowParallelLinear(_LinearBase):
@@ -295,7 +312,7 @@ class RowParallelLinear(_LinearBase):
         if in_dim is not None:
             depth = param.data.shape[in_dim]
             loaded_weight = loaded_weight.narrow(in_dim, get_tensor_model_parallel_rank() * depth, depth)
-        _copy_shard(param.data, loaded_weight)
+        _copy_shard(param.data, loaded_weight, param)
 
     def forward(self, input_: torch.Tensor):
         if self.input_is_parallel:
