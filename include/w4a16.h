@@ -151,6 +151,16 @@ int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const
                                   void* stream);
 
 /*
+ * w4a16_gemm_packed_f16_batched with an explicit launch shape, for tuning and tests:
+ * (mt, t, a, 0) = the streaming kernel with a waves (see w4a16_gemm_packed_f16_cfg),
+ * (mt, t, a, b) with b > 0 = the LDS-staged kernel with nw = a, kw = b.
+ */
+int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, const void* packed_w,
+                                      const void* packed_sz, const void* bias, void* out,
+                                      long long out_batch_stride, int M, int K, int N, int G,
+                                      int batch, int mt, int t, int a, int b, void* stream);
+
+/*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16
  * on the tensors the buffers were packed from).
  */

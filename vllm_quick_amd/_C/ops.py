@@ -208,7 +208,8 @@ def awq_repack_batch(kernels, scaling_factors, zeros) -> PackedAWQBatch:
 
 def awq_gemm_packed_batched(in_feats: torch.Tensor,
                             packed: PackedAWQBatch,
-                            bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            bias: Optional[torch.Tensor] = None,
+                            cfg: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
     """One launch for E GEMMs of one shape: in_feats [M, K] (shared by all problems) or [E, M, K] fp16,
     optional bias [E, N] -> [E, M, N] fp16.  Stands in for the reference's loop over experts
     (mixtral_quant.py:145-157)."""
@@ -241,10 +242,15 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
             raise ValueError("M * K must be a multiple of 8 for per-problem activations")
         if (M * packed.N) % 4:
             raise ValueError("M * N must be a multiple of 4")
-        check(
-            lib.w4a16_gemm_packed_f16_batched(x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
-                                              packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * packed.N, M,
-                                              packed.K, packed.N, packed.G, E, _stream()), "awq_gemm_batched")
+        common = (x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
+                  packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * packed.N, M, packed.K, packed.N,
+                  packed.G, E)
+        if cfg is None:
+            rc = lib.w4a16_gemm_packed_f16_batched(*common, _stream())
+        else:  # (mt, t, waves) = streaming kernel, (mt, t, nw, kw) = LDS-staged kernel
+            mt, t, a = cfg[:3]
+            rc = lib.w4a16_gemm_packed_f16_batched_cfg(*common, mt, t, a, cfg[3] if len(cfg) == 4 else 0, _stream())
+        check(rc, "awq_gemm_batched")
     return out
 
 

@@ -114,7 +114,9 @@ class MixtralMoE(torch.nn.Module):
         routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
         routing_weights /= routing_weights.sum(dim=-1, keepdim=True)
         dense = torch.zeros_like(router_logits, dtype=torch.float).scatter_(1, selected_experts, routing_weights)
-        return dense[:, self.expert_indicies]
+        # the local experts are a contiguous range (np.array_split of a range): a slice, not an index
+        # tensor, keeps this capturable in a HIP graph
+        return dense[:, self.expert_indicies[0]:self.expert_indicies[-1] + 1]
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         batch_size, sequence_length, hidden_dim = hidden_states.shape
