@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   sweep          per-M kernel times of the whole M sweep, N = 1 only,
   cpu_baseline   torch.matmul(x, dequant(W)) with the oracle's dequantiser on the host cores, N = 1 only,
   decode         Llama-2-7B-AWQ-shaped greedy decode tokens/s (benchmarks/llama_decode.py), N = 1 only,
+  experts        Mixtral-8x7B-shaped expert block, batched launches vs per-expert loop, N = 1 only,
   tp             column-/row-parallel halves of the step timed separately.
 """
 from __future__ import annotations
@@ -145,7 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--no-decode", action="store_true", help="skip the Llama-2-7B-shaped decode harness")
+    ap.add_argument("--no-decode", action="store_true", help="skip the Llama-2-7B-shaped decode harness and the Mixtral-shaped experts block")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
     args = ap.parse_args()
 
@@ -344,6 +345,10 @@ def main():
             torch.cuda.empty_cache()
             from benchmarks.llama_decode import run as decode_run
             out["decode"] = decode_run("7b", (1, 8, 64), device=device)
+            torch.cuda.empty_cache()
+            # small-M batched path: Mixtral-8x7B-shaped expert block, batched launches vs per-expert loop
+            from benchmarks.mixtral_experts import run as experts_run
+            out["experts"] = experts_run((1, 16), device=device)
 
     if rank == 0:
         print(json.dumps(out))

@@ -31,13 +31,13 @@ def short(name):
 
 
 def one(pattern):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True)
     if not files:
         raise SystemExit(f"missing {pattern}")
     return files[0]
 
 
-rows = list(csv.DictReader(open(one(f"{tag}_trace/*/*kernel_stats.csv"))))
+rows = list(csv.DictReader(open(one(f"{tag}_trace/**/*kernel_stats.csv"))))
 with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "calls", "avg_ns", "min_ns", "max_ns", "stddev_ns", "pct_of_gpu_time"])
@@ -58,8 +58,8 @@ def per_kernel(path, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
-fetch = per_kernel(one(f"{tag}_pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
-write = per_kernel(one(f"{tag}_pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
+fetch = per_kernel(one(f"{tag}_pmc_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+write = per_kernel(one(f"{tag}_pmc_write/**/*counter_collection.csv"), "WRITE_SIZE")
 traffic = {"_note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes; "
                     "FETCH_SIZE doubled per the gfx950 half-count of 16-byte-per-lane streaming reads",
            "kernels": {}}
