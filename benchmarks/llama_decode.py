@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from vllm_quick_amd._C import ops  # noqa: E402,F401
+from vllm_quick_amd.layers.activation import gate_up_silu_and_mul  # noqa: E402
 from vllm_quick_amd.layers.linear import (MergedColumnParallelLinear, QKVParallelLinear,  # noqa: E402
                                           RowParallelLinear)
 from vllm_quick_amd.layers.quantization import AWQConfig  # noqa: E402
@@ -69,6 +70,7 @@ class DecoderLayer(torch.nn.Module):
                                                        params_dtype=torch.float16, linear_method=method)
         self.down_proj = RowParallelLinear(cfg["inter"], h, bias=False, params_dtype=torch.float16,
                                            linear_method=method)
+        self.fuse_act = True
         self.ln1 = torch.ones(h, dtype=torch.float16, device=device)
         self.ln2 = torch.ones(h, dtype=torch.float16, device=device)
         self.k_cache = torch.zeros(max_bs, self.n_kv, max_len, self.head_dim, dtype=torch.float16, device=device)
@@ -103,17 +105,25 @@ class DecoderLayer(torch.nn.Module):
         o, _ = self.o_proj(att.reshape(bs, -1))
         x = x + o
         hdn = self.rms(x, self.ln2)
-        gu, _ = self.gate_up_proj(hdn)
-        g, u = gu.chunk(2, -1)
-        d, _ = self.down_proj(F.silu(g) * u)
+        if self.fuse_act:
+            act = gate_up_silu_and_mul(self.gate_up_proj, hdn)  # activation in the GEMM epilogue
+        else:
+            gu, _ = self.gate_up_proj(hdn)
+            g, u = gu.chunk(2, -1)
+            act = F.silu(g) * u
+        d, _ = self.down_proj(act)
         return x + d
 
     def linears_only(self, x):
         """The four W4A16 GEMMs of the layer with no other work (the hot path's share of a step)."""
         a, _ = self.qkv_proj(x)
         b, _ = self.o_proj(a[:, :self.o_proj.input_size_per_partition].contiguous())
-        c, _ = self.gate_up_proj(b)
-        d, _ = self.down_proj(c[:, :self.down_proj.input_size_per_partition].contiguous())
+        if self.fuse_act:
+            c = gate_up_silu_and_mul(self.gate_up_proj, b)
+        else:
+            c, _ = self.gate_up_proj(b)
+            c = c[:, :self.down_proj.input_size_per_partition].contiguous()
+        d, _ = self.down_proj(c)
         return d
 
 
@@ -176,12 +186,15 @@ def time_graph(fn, stream, reps=20):
     return ts[len(ts) // 2]
 
 
-def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None):
+def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None,
+        fuse_act=True):
     cfg = SHAPES[model_name]
     device = device or torch.device("cuda", torch.cuda.current_device())
     n_layers = n_layers or cfg["layers"]
     with torch.inference_mode():
         model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device)
+        for layer in model.layers:
+            layer.fuse_act = fuse_act
         stream = torch.cuda.Stream(device=device)
         res = {}
         for bs in batch_sizes:
@@ -198,6 +211,7 @@ def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ct
             }
     return {"model": f"llama-2-{model_name}-awq-shaped (synthetic weights, g128)", "layers_run": n_layers,
             "layers_model": cfg["layers"], "context": ctx_len, "tp": ps.get_tensor_model_parallel_world_size(),
+            "gate_up_activation": "fused into the GEMM epilogue" if fuse_act else "separate elementwise ops",
             "by_batch": res}
 
 
@@ -207,6 +221,7 @@ def main():
     ap.add_argument("--bs", default="1,2,4,8,16,32,64")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=128)
+    ap.add_argument("--no-fuse-act", action="store_true", help="run gate_up GEMM and silu-and-mul as separate ops")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -216,7 +231,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         ps.initialize_model_parallel(world)
     t0 = time.time()
-    out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx)
+    out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx, fuse_act=not a.no_fuse_act)
     out["wall_s"] = time.time() - t0
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(out))

@@ -161,6 +161,26 @@ int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, c
                                       int batch, int mt, int t, int a, int b, void* stream);
 
 /*
+ * The general form: batched (batch >= 1, strides as for w4a16_gemm_packed_f16_batched; ignored for
+ * batch == 1) with a fused epilogue and an optional explicit launch shape (mt == 0: chosen by the
+ * library; otherwise as for w4a16_gemm_packed_f16_batched_cfg).
+ *   W4A16_EPI_NONE      out [M, N]   = x @ W (+ bias)
+ *   W4A16_EPI_SILU_MUL  out [M, N/2] = silu(g) * u, where [g | u] = x @ W (+ bias) are the two halves
+ *                       of the N columns (N a multiple of 32): the merged gate_up projection of a
+ *                       gated MLP followed by its activation.  Replaces the GEMM + `silu_and_mul`
+ *                       pair of vllm/model_executor/models/llama.py:74-80
+ *                       (csrc/activation_kernels.cu:9-34): silu in fp32 on the fp16 GEMM result,
+ *                       rounded to fp16, then an fp16 multiply, as there; the [M, N] intermediate
+ *                       never reaches memory.  Built launch shapes only (W4A16_E_SHAPE otherwise).
+ * out_batch_stride >= M * (columns of out).
+ */
+enum { W4A16_EPI_NONE = 0, W4A16_EPI_SILU_MUL = 1 };
+int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void* packed_w,
+                             const void* packed_sz, const void* bias, void* out,
+                             long long out_batch_stride, int M, int K, int N, int G, int batch,
+                             int epilogue, int mt, int t, int a, int b, void* stream);
+
+/*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16
  * on the tensors the buffers were packed from).
  */

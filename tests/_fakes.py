@@ -47,3 +47,14 @@ class FakeOps:
                                   qz.detach().numpy()))
             outs.append(y if bias is None else y + bias[e])
         return torch.stack(outs)
+
+    def awq_gemm_packed_silu_and_mul(self, x, packed, bias=None, cfg=None):
+        self.trace.append(["awq_gemm_silu_and_mul", list(x.shape)])
+        if isinstance(packed, list):  # a batch: list of (qweight, scales, qzeros)
+            y = self.awq_gemm_packed_batched(x, packed, bias)
+        else:
+            y = self.awq_gemm_packed(x, packed, bias)
+        self.trace.pop()
+        half = y.shape[-1] // 2
+        g = y[..., :half].float()
+        return (g / (1.0 + torch.exp(-g))).half() * y[..., half:]

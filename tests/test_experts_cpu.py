@@ -74,9 +74,10 @@ def test_batched_block_matches_reference_loop(monkeypatch):
     x = (np.random.default_rng(5).standard_normal((2, 3, 64)) * 0.5).astype(np.float16)
     y = moe(torch.from_numpy(x))
     assert y.shape == (2, 3, 64) and y.dtype == torch.float16
-    calls = [t for t in fake.trace if t[0] == "awq_gemm_batched"]
-    # three launches in all: 2E gate/up problems on the shared tokens, E down projections
-    assert calls == [["awq_gemm_batched", [6, 64], 8], ["awq_gemm_batched", [4, 6, 96], 4]]
+    calls = [t for t in fake.trace if t[0].startswith("awq_gemm")]
+    # two launches in all: E [w1 | w3] problems on the shared tokens with the activation fused,
+    # E down projections
+    assert calls == [["awq_gemm_silu_and_mul", [6, 64]], ["awq_gemm_batched", [4, 6, 96], 4]]
     want = reference_block(x.reshape(6, 64), gate, ck, moe.expert_indicies, 2)
     assert np.allclose(y.reshape(6, 64).numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=2e-3)
     # the re-layout is cached until a weight is written again
@@ -86,6 +87,19 @@ def test_batched_block_matches_reference_loop(monkeypatch):
         moe.experts[1].w2.qweight.add_(0)
     moe(torch.from_numpy(x))
     assert [t[0] for t in fake.trace].count("repack_batch") == 4
+
+
+def test_separate_activation_route(monkeypatch):
+    moe, fake = make(monkeypatch)
+    assert moe.fuse_act  # K of w2 is a multiple of the group size, hence of 16: always tile-aligned
+    moe.fuse_act = False
+    ck, gate = fill(moe, seed=8)
+    x = (np.random.default_rng(9).standard_normal((1, 4, 64)) * 0.5).astype(np.float16)
+    y = moe(torch.from_numpy(x))
+    calls = [t for t in fake.trace if t[0].startswith("awq_gemm")]
+    assert calls == [["awq_gemm_batched", [4, 64], 8], ["awq_gemm_batched", [4, 4, 96], 4]]
+    want = reference_block(x.reshape(4, 64), gate, ck, moe.expert_indicies, 2)
+    assert np.allclose(y.reshape(4, 64).numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=2e-3)
 
 
 def test_unbatched_fallback_is_the_reference_loop(monkeypatch):

@@ -260,3 +260,28 @@ def test_weight_loader_after_a_forward_invalidates_the_packed_copy(monkeypatch):
         want = orc.gemm_faithful(x.numpy(), ck["qweight"], ck["scales"], ck["qzeros"])
         assert np.allclose(out.detach().numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2, atol=1e-3)
     assert [t[0] for t in fake.trace].count("repack") == 2
+
+
+def test_gate_up_silu_and_mul_uses_the_fused_call(monkeypatch):
+    """A merged gate_up projection + SiluAndMul (llama.py:74-80): one fused operator call below the
+    large-batch switch point, GEMM then activation above it; same values either way."""
+    from vllm_quick_amd.layers.activation import SiluAndMul, gate_up_silu_and_mul
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = awq_mod.AWQLinearMethod(AWQConfig(4, 32, True), fp16_matmul_threshold=4)
+    layer = L.MergedColumnParallelLinear(64, [64, 64], bias=False, params_dtype=torch.float16, linear_method=method)
+    gate, up = ckpt(64, 64, 21), ckpt(64, 64, 22)
+    for i, ck in enumerate((gate, up)):
+        for n in ck:
+            p = getattr(layer, n)
+            p.weight_loader(p, torch.from_numpy(ck[n]), i)
+    for tokens, want_ops in ((3, ["awq_gemm_silu_and_mul"]), (4, ["awq_dequantize"])):
+        x = torch.from_numpy(orc.make_inputs(tokens, 64, 64, 32, seed=23)[0])
+        del fake.trace[:]
+        y = gate_up_silu_and_mul(layer, x)
+        assert [t[0] for t in fake.trace if t[0] != "repack"] == want_ops
+        g = torch.from_numpy(orc.gemm_faithful(x.numpy(), gate["qweight"], gate["scales"], gate["qzeros"]))
+        u = torch.from_numpy(orc.gemm_faithful(x.numpy(), up["qweight"], up["scales"], up["qzeros"]))
+        want = SiluAndMul()(torch.cat([g, u], -1))
+        assert y.shape == (tokens, 64)
+        assert np.allclose(y.float().numpy(), want.float().numpy(), rtol=2e-2, atol=2e-3)

@@ -254,6 +254,53 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
     return out
 
 
+EPI_NONE, EPI_SILU_MUL = 0, 1
+
+
+def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
+                                 packed,
+                                 bias: Optional[torch.Tensor] = None,
+                                 cfg: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+    """silu(x @ W[:, :N/2]) * (x @ W[:, N/2:]) in one launch: the merged gate_up projection of a gated
+    MLP with its activation fused into the GEMM epilogue (llama.py:74-80 of the reference runs the GEMM,
+    then `silu_and_mul`).  `packed` is a PackedAWQ ([M, K] -> [M, N/2]) or a PackedAWQBatch ([M, K] shared
+    or [E, M, K] -> [E, M, N/2]); bias, if given, covers all N columns."""
+    _require(in_feats, torch.float16, "in_feats")
+    batched = isinstance(packed, PackedAWQBatch)
+    E = packed.batch if batched else 1
+    if packed.N % 32:
+        raise ValueError("the fused activation needs two halves of whole 16-column tiles (N % 32 == 0)")
+    if in_feats.shape[-1] != packed.K or in_feats.dim() not in ((2, 3) if batched else (2, )):
+        raise ValueError(f"in_feats must be [M, {packed.K}]" + (f" or [{E}, M, {packed.K}]" if batched else "") +
+                         f", got {tuple(in_feats.shape)}")
+    shared = in_feats.dim() == 2
+    if not shared and in_feats.shape[0] != E:
+        raise ValueError(f"in_feats must carry {E} problems, got {in_feats.shape[0]}")
+    if in_feats.device != packed.device:
+        raise RuntimeError("in_feats and the packed weights are on different devices")
+    x = in_feats.contiguous()
+    M, half = x.shape[-2], packed.N // 2
+    bias_ptr = None
+    if bias is not None:
+        _require(bias, torch.float16, "bias")
+        if bias.numel() != E * packed.N:
+            raise ValueError(f"bias must have {E * packed.N} elements")
+        bias = bias.contiguous()
+        bias_ptr = bias.data_ptr()
+    with _on_device(x.device):
+        out = torch.empty((E, M, half) if batched else (M, half), dtype=torch.float16, device=x.device)
+        if M == 0:
+            return out
+        if batched and ((M * half) % 4 or (not shared and (M * packed.K) % 8)):
+            raise ValueError("per-problem buffers must stay 8-byte (out) / 16-byte (in_feats) aligned")
+        mt, t, a, b = (0, 0, 0, 0) if cfg is None else (tuple(cfg) + (0, ))[:4]
+        rc = lib.w4a16_gemm_packed_f16_ex(x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
+                                          packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * half, M,
+                                          packed.K, packed.N, packed.G, E, EPI_SILU_MUL, mt, t, a, b, _stream())
+        check(rc, "awq_gemm_silu_and_mul")
+    return out
+
+
 def awq_gemm_stock(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors: torch.Tensor,
                    zeros: torch.Tensor) -> torch.Tensor:
     """Shape-agnostic GEMM straight from the stock tensors (no repack, nothing cached)."""

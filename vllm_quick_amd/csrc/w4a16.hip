@@ -112,6 +112,20 @@ __device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c) {
   return dequant_word(w, c, k);
 }
 
+// out = silu(gate) * up on fp16 GEMM results, as the reference's activation kernel computes it
+// (csrc/activation_kernels.cu:9-34): silu in fp32 on the fp16 value, rounded to fp16, then an
+// fp16 multiply.
+__device__ __forceinline__ f16x4 silu_mul(f16x4 g, f16x4 u) {
+  f16x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = (float)g[i];
+    const f16 sg = (f16)(x / (1.0f + expf(-x)));
+    r[i] = sg * u[i];
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------------------
 // GEMM on the private layout
 // ---------------------------------------------------------------------------
@@ -160,11 +174,16 @@ __device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
 // W  : wavefronts per workgroup (they split K)
 // SZS: k-steps (of 32) covered by one scale/zero word: 4 when G % 128 == 0,
 //      2 when G == 64, 1 for any other multiple of 32
-template <int MT, int T, int W, int SZS>
+// ACT: the weight is [gate | up] (two halves of N/2 columns, N/2 a multiple of 16); the workgroup
+//      takes T/2 column tiles of each half and stores silu(gate) * up, an [M, N/2] output.
+template <int MT, int T, int W, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) {
   const GemmArgs a = batch_slice(ga);
   constexpr int NSZ = 4 / SZS;  // scale/zero words per 128-k block and tile
   constexpr int TM = T * MT;
+  constexpr int H = ACT ? T / 2 : T;       // tiles per half
+  static_assert(!ACT || T % 2 == 0, "gate and up tiles come in pairs");
+  const int NTH = ACT ? a.NT / 2 : a.NT;   // column tiles per half
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
 
@@ -172,7 +191,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n16 = lane & 15;
   const int kq = lane >> 4;
-  const int nt0 = blockIdx.x * T;
+  const int nt0 = blockIdx.x * H;
   const int m0 = blockIdx.y * (MT * 16);
 
   const u32x4* wp[T];
@@ -180,7 +199,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     // Tiles past the end re-read the last tile (valid memory); their results are dropped.
-    const int nt = min(nt0 + t, a.NT - 1);
+    const int nt = min(nt0 + (t % H), NTH - 1) + (t / H) * NTH;
     wp[t] = a.pw + (size_t)nt * a.KBS * 64 + lane;
     szp[t] = a.psz + (size_t)nt * a.NG * 16 + n16;
   }
@@ -299,24 +318,33 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   // Cross-wave reduction through LDS: fold the upper half of the live waves onto the
   // lower half until LIVE partial sets fit the budget, then every wave sums whole tiles.
   constexpr int LIVE = live_waves(W, TM);
-  auto store_tile = [&](int i, f32x4 v) {
-    // C layout of the MFMA: register r of lane l is row 4 (l >> 4) + r of the tile
-    // (a column n of `out`), column l & 15 (a row m of `out`).
+  // C layout of the MFMA: register r of lane l is row 4 (l >> 4) + r of the tile (a column n of
+  // `out`), column l & 15 (a row m of `out`).  Values are rounded to fp16 first, then the bias is
+  // added in fp16: the value of `out + bias` on an fp16 GEMM result (awq.py:163-164).
+  auto finish = [&](f32x4 v, int n_bias) {
+    f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+    if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+    return h;
+  };
+  // i indexes (t, mt) pairs of the first H tiles; with ACT `vu` is the matching tile of the up half
+  auto store_tile = [&](int i, f32x4 v, f32x4 vu) {
     const int t = i / MT, mt = i - t * MT;
     const int nt = nt0 + t;
     const int n = nt * 16 + kq * 4;
     const int m = m0 + mt * 16 + n16;
-    if (nt < a.NT && n < a.N && m < a.M) {
-      // Round to fp16 first, then add the bias in fp16: the value of `out + bias`
-      // on an fp16 GEMM result (awq.py:163-164).
-      f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
-      *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
+    if constexpr (ACT) {
+      const int NH = a.N / 2;
+      if (nt < NTH && m < a.M)
+        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+    } else {
+      if (nt < a.NT && n < a.N && m < a.M) *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = finish(v, n);
     }
   };
+  constexpr int OUTS = H * MT;  // stores per workgroup: tiles, or gate/up tile pairs
   if constexpr (W == 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) store_tile(i, acc[i / MT][i % MT]);
+    for (int i = 0; i < OUTS; ++i)
+      store_tile(i, acc[i / MT][i % MT], acc[(i / MT + (ACT ? H : 0)) % T][i % MT]);
   } else {
 #pragma unroll
     for (int cur = W; cur > LIVE; cur >>= 1) {
@@ -337,11 +365,18 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       for (int i = 0; i < TM; ++i) red[(w * TM + i) * 64 + lane] = acc[i / MT][i % MT];
     }
     __syncthreads();
-    for (int i = w; i < TM; i += W) {
+    for (int i = w; i < OUTS; i += W) {
       f32x4 v = red[i * 64 + lane];
 #pragma unroll
       for (int s = 1; s < LIVE; ++s) v += red[(s * TM + i) * 64 + lane];
-      store_tile(i, v);
+      f32x4 vu = v;
+      if constexpr (ACT) {
+        const int iu = i + OUTS;
+        vu = red[iu * 64 + lane];
+#pragma unroll
+        for (int s = 1; s < LIVE; ++s) vu += red[(s * TM + iu) * 64 + lane];
+      }
+      store_tile(i, v, vu);
     }
   }
 }
@@ -374,11 +409,16 @@ __device__ unsigned long long g_stamps[4096 * 32];
 #define STAMP(slot) do {} while (0)
 #endif
 
-template <int MT, int T, int NW, int KW, int SZS>
+// ACT (gate | up weight, silu(gate) * up stored, see gemm_packed_kernel): the first NW / 2 waves of a
+// K-group take the workgroup's gate columns, the others the matching up columns.
+template <int MT, int T, int NW, int KW, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs ga, int n_slices,
                                                                    int m_blocks) {
   const GemmArgs a = batch_slice(ga);
   constexpr int NWAVES = NW * KW;
+  constexpr int HW = ACT ? NW / 2 : NW;    // waves per half
+  static_assert(!ACT || NW % 2 == 0, "gate and up waves come in pairs");
+  const int NTH = ACT ? a.NT / 2 : a.NT;   // column tiles per half
   constexpr int NSZ = 4 / SZS;
   constexpr int ROWS = MT * 16;
   constexpr int SLAB = ROWS * 256;                       // bytes: ROWS x 128 k of fp16
@@ -401,14 +441,14 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   const int slice = (idx / m_blocks) * 8 + xcd;
   const int mb = idx % m_blocks;
   if (slice >= n_slices) return;  // whole workgroup: no barrier is skipped by a subset
-  const int nt0 = (slice * NW + nw) * T;
+  const int nt0 = (slice * HW + nw % HW) * T;
   const int m0 = mb * ROWS;
 
   const u32x4* wp[T];
   const uint32_t* szp[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const int nt = min(nt0 + t, a.NT - 1);
+    const int nt = min(nt0 + t, NTH - 1) + (nw / HW) * NTH;
     wp[t] = a.pw + (size_t)nt * a.KBS * 64 + lane;
     szp[t] = a.psz + (size_t)nt * a.NG * 16 + n16;
   }
@@ -592,19 +632,34 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(const GemmArgs
   for (int i = 0; i < TM; ++i) red[((kg * NW + nw) * TM + i) * 64 + lane] = acc[i / MT][i % MT];
   __syncthreads();
   STAMP(3);
-  for (int o = w; o < NW * TM; o += NWAVES) {
+  for (int o = w; o < HW * TM; o += NWAVES) {
     const int onw = o / TM, i = o - onw * TM;
     f32x4 v = red[(onw * TM + i) * 64 + lane];
 #pragma unroll
     for (int g = 1; g < KW; ++g) v += red[((g * NW + onw) * TM + i) * 64 + lane];
     const int t = i / MT, mt = i - t * MT;
-    const int nt = (slice * NW + onw) * T + t;
+    const int nt = (slice * HW + onw) * T + t;
     const int n = nt * 16 + kq * 4;
     const int m = m0 + mt * 16 + n16;
-    if (nt < a.NT && n < a.N && m < a.M) {
-      f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
-      *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
+    f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+    if constexpr (ACT) {
+      f32x4 vu = red[((HW + onw) * TM + i) * 64 + lane];
+#pragma unroll
+      for (int g = 1; g < KW; ++g) vu += red[((g * NW + HW + onw) * TM + i) * 64 + lane];
+      const int NH = a.N / 2;
+      if (nt < NTH && m < a.M) {
+        f16x4 hu = f16x4{(f16)vu.x, (f16)vu.y, (f16)vu.z, (f16)vu.w};
+        if (a.bias != nullptr) {
+          h += *reinterpret_cast<const f16x4*>(a.bias + n);
+          hu += *reinterpret_cast<const f16x4*>(a.bias + NH + n);
+        }
+        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(h, hu);
+      }
+    } else {
+      if (nt < a.NT && n < a.N && m < a.M) {
+        if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
+        *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
+      }
     }
   }
   STAMP(4);
@@ -850,7 +905,7 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   if (batch != 1) {
     if (batch < 1 || batch > 65535) return W4A16_E_SHAPE;
     // every problem's buffers must keep the alignment the kernels rely on
-    if (x_batch_stride < 0 || x_batch_stride % 8 || out_batch_stride < (long long)M * N || out_batch_stride % 4)
+    if (x_batch_stride < 0 || x_batch_stride % 8 || out_batch_stride < 0 || out_batch_stride % 4)
       return W4A16_E_SHAPE;
     a->x_bs = x_batch_stride;
     a->out_bs = out_batch_stride;
@@ -861,13 +916,29 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   return W4A16_OK;
 }
 
+// The fused-activation variants are built for the row counts the streaming kernel serves by default.
+template <int MT, int T>
+constexpr bool kActStreaming = (T % 2 == 0) && MT <= 2;
+
 template <int MT, int T, int W>
-int launch_packed(const GemmArgs& a, hipStream_t s, int batch) {
+int launch_packed(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   const size_t lds = (size_t)reduce_lds_tiles(W, T * MT) * 1024;
-  const dim3 grid(ceil_div(a.NT, T), ceil_div(a.M, MT * 16), batch);
+  const int tiles = act ? a.NT / 2 : a.NT, per_wg = act ? T / 2 : T;
+  const dim3 grid(ceil_div(tiles, per_wg), ceil_div(a.M, MT * 16), batch);
   const dim3 block(64 * W);
   void (*kern)(const GemmArgs) = nullptr;
-  if (a.G % 128 == 0)
+  if (act) {
+    if constexpr (kActStreaming<MT, T>) {
+      if (a.G % 128 == 0)
+        kern = gemm_packed_kernel<MT, T, W, 4, true>;
+      else if (a.G == 64)
+        kern = gemm_packed_kernel<MT, T, W, 2, true>;
+      else
+        kern = gemm_packed_kernel<MT, T, W, 1, true>;
+    } else {
+      return W4A16_E_SHAPE;
+    }
+  } else if (a.G % 128 == 0)
     kern = gemm_packed_kernel<MT, T, W, 4>;
   else if (a.G == 64)
     kern = gemm_packed_kernel<MT, T, W, 2>;
@@ -887,17 +958,31 @@ int launch_packed(const GemmArgs& a, hipStream_t s, int batch) {
 }
 
 template <int MT, int T, int NW, int KW>
-int launch_tiled(const GemmArgs& a, hipStream_t s, int batch) {
+constexpr bool kActTiled = (NW % 2 == 0) && (MT == 4 || (MT == 2 && NW == 2)) && T == 3;
+
+template <int MT, int T, int NW, int KW>
+int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   constexpr int stage = 2 * KW * MT * 16 * 256;         // double-buffered slabs
   constexpr int reduce = NW * KW * T * MT * 1024;       // partial tiles
   constexpr int lds = stage > reduce ? stage : reduce;
   static_assert(lds <= 160 * 1024, "LDS budget");
   if (a.KBS % KW) return W4A16_E_SHAPE;
-  const int n_slices = ceil_div(a.NT, NW * T);
+  const int n_slices = act ? ceil_div(a.NT / 2, NW / 2 * T) : ceil_div(a.NT, NW * T);
   const int m_blocks = ceil_div(a.M, MT * 16);
   const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
   void (*kern)(const GemmArgs, int, int) = nullptr;
-  if (a.G % 128 == 0)
+  if (act) {
+    if constexpr (kActTiled<MT, T, NW, KW>) {
+      if (a.G % 128 == 0)
+        kern = gemm_tiled_kernel<MT, T, NW, KW, 4, true>;
+      else if (a.G == 64)
+        kern = gemm_tiled_kernel<MT, T, NW, KW, 2, true>;
+      else
+        kern = gemm_tiled_kernel<MT, T, NW, KW, 1, true>;
+    } else {
+      return W4A16_E_SHAPE;
+    }
+  } else if (a.G % 128 == 0)
     kern = gemm_tiled_kernel<MT, T, NW, KW, 4>;
   else if (a.G == 64)
     kern = gemm_tiled_kernel<MT, T, NW, KW, 2>;
@@ -920,9 +1005,10 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch) {
   X(4, 2, 3, 4) X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
   X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4)
 
-int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1) {
+int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1,
+                   bool act = false) {
 #define X(MT_, T_, NW_, KW_) \
-  if (mt == MT_ && t == T_ && nw == NW_ && kw == KW_) return launch_tiled<MT_, T_, NW_, KW_>(a, s, batch);
+  if (mt == MT_ && t == T_ && nw == NW_ && kw == KW_) return launch_tiled<MT_, T_, NW_, KW_>(a, s, batch, act);
   W4A16_FOR_EACH_TILED(X)
 #undef X
   return W4A16_E_SHAPE;
@@ -942,9 +1028,10 @@ int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t
   X(8, 1, 8)  X(8, 2, 8)  X(8, 3, 8)                                      \
   X(8, 1, 4)  X(8, 2, 4)  X(8, 3, 4)
 
-int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1) {
+int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1,
+                    bool act = false) {
 #define X(MT_, T_, W_) \
-  if (mt == MT_ && t == T_ && waves == W_) return launch_packed<MT_, T_, W_>(a, s, batch);
+  if (mt == MT_ && t == T_ && waves == W_) return launch_packed<MT_, T_, W_>(a, s, batch, act);
   W4A16_FOR_EACH_CFG(X)
 #undef X
   return W4A16_E_SHAPE;
@@ -969,7 +1056,7 @@ struct Choice {
   int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
 };
 
-Choice choose_cfg(int M, int K, int N, int batch = 1) {
+Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
@@ -984,6 +1071,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1) {
     if (MT == 1 && KB >= 8) {
       if (tiles >= 16 * cus) return Choice{false, 1, 4, 4, 0};
       if (tiles >= 6 * cus) return Choice{false, 1, 2, 8, 0};
+    }
+    if (act) {
+      // gate/up tile pairs: an even T from the fused-activation instantiations
+      int Tt = 2 * ceil_div(tiles / 2, cus);
+      if (MT == 1 && Tt == 2 && Wv == 16) return Choice{false, 1, 2, 16, 0};
+      if (Wv > 8) Wv = 8;
+      const int tmax = (MT == 1) ? (Wv == 8 ? 8 : 4) : (Wv == 8 ? 6 : 2);
+      if (Tt > tmax) Tt = tmax;
+      return Choice{false, MT, Tt, Wv, 0};
     }
     int Tt = ceil_div(tiles, cus);  // one workgroup per CU (registers and LDS admit no second one)
     if (Tt < 1) Tt = 1;
@@ -1003,6 +1099,7 @@ Choice choose_cfg(int M, int K, int N, int batch = 1) {
   for (const auto& c : cand) {
     const int mt = c[0], t = c[1], nw = c[2], kw = c[3];
     if (mtiles <= 4 && mt == 4 && mtiles <= 2) continue;
+    if (act && (nw % 2 || t != 3)) continue;  // fused-activation instantiations: see kActTiled
     const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt) * batch;
     const double rounds = (double)ceil_div(ctas, cus);
     double cost = rounds * mt * t * nw;               // matrix work per workgroup
@@ -1158,31 +1255,60 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
                                    stream);
 }
 
-int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, const void* packed_w,
-                                      const void* packed_sz, const void* bias, void* out,
-                                      long long out_batch_stride, int M, int K, int N, int G, int batch,
-                                      int mt, int t, int a_, int b_, void* stream) {
+// Shared body of the batched / fused-epilogue entry points.  mt == 0: pick the launch shape.
+static int gemm_packed_general(const void* x, long long x_batch_stride, const void* packed_w,
+                               const void* packed_sz, const void* bias, void* out,
+                               long long out_batch_stride, int M, int K, int N, int G, int batch,
+                               int epilogue, int mt, int t, int a_, int b_, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
+  if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL) return W4A16_E_SHAPE;
+  const bool act = epilogue == W4A16_EPI_SILU_MUL;
+  if (act && N % 32) return W4A16_E_SHAPE;  // two halves of whole 16-column tiles
+  const long long out_cols = act ? N / 2 : N;
   GemmArgs a;
+  // a single problem needs no strides; give fill_args consistent ones anyway
   const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G, batch, x_batch_stride,
-                           out_batch_stride);
+                           batch == 1 ? (long long)M * N : out_batch_stride);
   if (rc) return rc;
+  if (batch != 1) {
+    if (out_batch_stride < M * out_cols || out_batch_stride % 4) return W4A16_E_SHAPE;
+    a.out_bs = out_batch_stride;
+  }
   if ((long long)batch * out_batch_stride >= (1LL << 40)) return W4A16_E_TOO_LARGE;
   clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
-  if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch);
-  return dispatch_packed(a, mt, t, a_, s, batch);
+  if (mt == 0) {
+    const Choice c = choose_cfg(M, K, N, batch, act);
+    mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
+  }
+  if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
+  return dispatch_packed(a, mt, t, a_, s, batch, act);
+}
+
+int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, const void* packed_w,
+                                      const void* packed_sz, const void* bias, void* out,
+                                      long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                      int mt, int t, int a, int b, void* stream) {
+  if (mt <= 0) return W4A16_E_SHAPE;
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
+                             N, G, batch, W4A16_EPI_NONE, mt, t, a, b, stream);
 }
 
 int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const void* packed_w,
                                   const void* packed_sz, const void* bias, void* out,
                                   long long out_batch_stride, int M, int K, int N, int G, int batch,
                                   void* stream) {
-  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
-  const Choice c = choose_cfg(M, K, N, batch);
-  return w4a16_gemm_packed_f16_batched_cfg(x, x_batch_stride, packed_w, packed_sz, bias, out,
-                                           out_batch_stride, M, K, N, G, batch, c.mt, c.t, c.a,
-                                           c.tiled ? c.b : 0, stream);
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
+                             N, G, batch, W4A16_EPI_NONE, 0, 0, 0, 0, stream);
+}
+
+int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void* packed_w,
+                             const void* packed_sz, const void* bias, void* out,
+                             long long out_batch_stride, int M, int K, int N, int G, int batch,
+                             int epilogue, int mt, int t, int a, int b, void* stream) {
+  if (mt < 0) return W4A16_E_SHAPE;
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
+                             N, G, batch, epilogue, mt, t, a, b, stream);
 }
 
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,

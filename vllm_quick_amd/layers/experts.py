@@ -9,11 +9,12 @@ local expert on all tokens, one AWQ GEMM launch at a time (3 launches per expert
 here the local experts' weights are kept back to back in the private layout and the block
 takes three launches in total:
 
-    [w1_0 .. w1_{E-1}, w3_0 .. w3_{E-1}]  x  tokens        2E problems, shared activations
-    silu(w1 out) * w3 out                                   elementwise (torch)
-    [w2_0 .. w2_{E-1}]                   x  per-expert act  E problems
+    [w1_e | w3_e], e = 0 .. E-1   x  tokens           E problems, shared activations, with
+                                                      silu(w1 out) * w3 out fused into the epilogue
+    [w2_0 .. w2_{E-1}]            x  per-expert act   E problems
 
-followed by the routing-weighted sum over experts.
+followed by the routing-weighted sum over experts.  (`fuse_act = False` runs 2E separate gate/up
+problems and the activation as an elementwise step instead.)
 """
 from __future__ import annotations
 
@@ -82,7 +83,8 @@ class MixtralMoE(torch.nn.Module):
         self.gate = ReplicatedLinear(hidden_size, num_total_experts, bias=False, params_dtype=params_dtype,
                                      linear_method=None)
         self.batched = isinstance(linear_method, AWQLinearMethod)
-        self._packed = None  # (stamp, w13 batch, w2 batch)
+        self.fuse_act = True  # the intermediate size is a multiple of the group size, hence of 16
+        self._packed = None  # (stamp, fused?, w13 batch, w2 batch)
 
     # ------------------------------------------------------------------
     def _stock(self, names):
@@ -96,15 +98,21 @@ class MixtralMoE(torch.nn.Module):
     def _batches(self):
         """The local experts' weights back to back in the private layout, rebuilt when any stock
         tensor was written since (weight loading)."""
-        w13, w2 = self._stock(("w1", "w3")), self._stock(("w2", ))
-        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for trio in w13 + w2 for t in trio)
-        if self._packed is not None and self._packed[0] == stamp:
+        w1, w3, w2 = self._stock(("w1", )), self._stock(("w3", )), self._stock(("w2", ))
+        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for trio in w1 + w3 + w2 for t in trio)
+        if self._packed is not None and self._packed[0] == (stamp, self.fuse_act):
             return self._packed[1], self._packed[2]
         if ops.stream_is_capturing():
             return None  # no re-layout inside a graph capture
-        b13 = ops.awq_repack_batch(*[[trio[i] for trio in w13] for i in (0, 1, 2)])
+        if self.fuse_act:
+            # one [K, 2 I] problem per expert: w1's columns, then w3's (all three AWQ tensors are
+            # column-major in the output dimension, so this is a concatenation along dim 1)
+            merged = [tuple(torch.cat([a, b], dim=1) for a, b in zip(t1, t3)) for t1, t3 in zip(w1, w3)]
+        else:
+            merged = w1 + w3  # 2E problems: every w1, then every w3
+        b13 = ops.awq_repack_batch(*[[trio[i] for trio in merged] for i in (0, 1, 2)])
         b2 = ops.awq_repack_batch(*[[trio[i] for trio in w2] for i in (0, 1, 2)])
-        self._packed = (stamp, b13, b2)
+        self._packed = ((stamp, self.fuse_act), b13, b2)
         return b13, b2
 
     def routing(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -132,8 +140,11 @@ class MixtralMoE(torch.nn.Module):
         else:
             b13, b2 = batches
             E = len(self.expert_indicies)
-            h13 = ops.awq_gemm_packed_batched(hidden_states, b13)  # [2E, T, I]
-            act = F.silu(h13[:E]) * h13[E:]
+            if self.fuse_act:
+                act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13)  # [E, T, I]
+            else:
+                h13 = ops.awq_gemm_packed_batched(hidden_states, b13)  # [2E, T, I]
+                act = F.silu(h13[:E]) * h13[E:]
             y = ops.awq_gemm_packed_batched(act, b2)  # [E, T, H]
             # each expert's output is scaled in fp32 and rounded to fp16 as `.mul_` does; the sum
             # over experts is taken in fp32 and rounded once

@@ -152,3 +152,20 @@ class AWQLinearMethod(LinearMethodBase):
         else:
             out = ops.awq_gemm_packed(reshaped_x, packed, bias=bias)
         return out.reshape(out_shape)
+
+    def apply_weights_silu_and_mul(self, weights: Dict[str, Any], x: torch.Tensor,
+                                   bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """silu(y[..., :N/2]) * y[..., N/2:] for y = apply_weights(weights, x, bias): the merged gate_up
+        projection of a gated MLP followed by `SiluAndMul` (llama.py:74-80), with the activation fused
+        into the GEMM epilogue where the fused kernel serves the call."""
+        qweight = weights["qweight"]
+        n_out = qweight.shape[-1] * self.quant_config.pack_factor
+        num_tokens = x.shape[:-1].numel()
+        large = self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold
+        packed = None if (large or n_out % 32) else self._packed(weights)
+        if packed is None:
+            y = self.apply_weights(weights, x, bias)
+            half = n_out // 2
+            return torch.nn.functional.silu(y[..., :half]) * y[..., half:]
+        out = ops.awq_gemm_packed_silu_and_mul(x.reshape(-1, x.shape[-1]), packed, bias=bias)
+        return out.reshape(x.shape[:-1] + (n_out // 2, ))
