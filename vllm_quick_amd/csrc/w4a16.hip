@@ -1071,6 +1071,10 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     if (MT == 1 && KB >= 8) {
       if (tiles >= 16 * cus) return Choice{false, 1, 4, 4, 0};
       if (tiles >= 6 * cus) return Choice{false, 1, 2, 8, 0};
+      // More than three tiles per CU (a 22016-wide gate_up layer): 16-wave workgroups of 3 tiles would
+      // run in two uneven rounds; 8-wave workgroups are all resident at once (12.6 vs 14.3 us at
+      // 1 row, 13.8 vs 16.3 us at 16 rows on 4096 x 22016).
+      if (!act && tiles > 3 * cus) return Choice{false, 1, M <= 8 ? 3 : 6, 8, 0};
     }
     if (act) {
       // gate/up tile pairs: an even T from the fused-activation instantiations
