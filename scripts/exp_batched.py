@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_quick_amd._C import ops
-from scripts.gpu_check import time_graph
+from scripts._timing import time_graph
 from bench import make_weights, make_x
 dev = torch.device("cuda:0")
 K, N, G = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4096,14336,128").split(","))

@@ -1,7 +1,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_quick_amd._C import ops
-from scripts.gpu_check import time_graph
+from scripts._timing import time_graph
 from bench import make_weights, make_x
 dev = torch.device("cuda:0")
 cfgs = [tuple(int(v) for v in c.split(",")) for c in sys.argv[1].split(";")]

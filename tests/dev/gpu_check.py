@@ -1,8 +1,9 @@
 """Developer check on a GPU box: parity of every kernel against the oracle on a few
 shapes, then a timing sweep over launch shapes.  Not part of the product; the
-pytest suite and bench.py are the maintained entry points.
+pytest suite and bench.py are the maintained entry points.  It lives under tests/ because it
+computes with the oracle.
 
-usage: python scripts/gpu_check.py [--quick] [--sweep]
+usage: python tests/dev/gpu_check.py [--quick] [--sweep]
 """
 import argparse
 import os
@@ -12,11 +13,12 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import awq_oracle as orc  # noqa: E402
 from vllm_quick_amd._C import ops  # noqa: E402
+from scripts._timing import time_graph  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -57,28 +59,6 @@ def check_shape(M, K, N, G, seed=0, cfgs=(None,)):
         print(f"   {name:24s} parity={'OK ' if good else 'BAD'} mismatch={(~close).mean():.2e} "
               f"max|d| vs faithful={err_f:.3e} vs exact={err_e:.3e} (faithful vs exact {ref_e:.3e})")
     return ok
-
-
-def time_graph(fn_list, iters=20):
-    """fn_list: callables each enqueuing one kernel.  Returns mean us per kernel, graph-replayed."""
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        for f in fn_list:
-            f()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
-            for f in fn_list:
-                f()
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
-        for _ in range(iters):
-            g.replay()
-        e1.record(s)
-        torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (iters * len(fn_list))
 
 
 def sweep(K=4096, N=11008, G=128, nbuf=16, only_m=None, cfg_override=None):
