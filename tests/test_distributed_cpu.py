@@ -1,4 +1,5 @@
-"""Tensor-parallel column/row sharding of the W4A16 linear with world_size 2 on the gloo backend.
+"""Tensor-parallel column/row sharding of the W4A16 linear, and the expert-parallel split of the
+mixture-of-experts block, with world_size 2 on the gloo backend.
 
 Each rank builds the reference-style layers on top of AWQLinearMethod (native ops replaced by
 the oracle-backed fakes: there is no GPU here), loads its shard of one full checkpoint through
@@ -80,6 +81,29 @@ def _worker(rank, world, port, q):
         y, ob = row(torch.from_numpy(x))
         assert ob is None
         assert np.allclose(y.detach().numpy().astype(np.float32), want + bias.float().numpy(), rtol=1e-2, atol=2e-3)
+
+        # mixture-of-experts block: the experts are split over the ranks (mixtral_quant.py:113-118),
+        # every rank runs its own on all tokens, one all-reduce sums the partial blocks
+        from vllm_quick_amd.layers import experts as X
+        from test_experts_cpu import fill, reference_block
+        X.ops = awq_mod.ops
+        moe = X.MixtralMoE(4, 2, 64, 96, linear_method=method, params_dtype=torch.float16)
+        assert moe.expert_indicies == [2 * rank, 2 * rank + 1]
+        assert [e is not None for e in moe.experts] == [i // 2 == rank for i in range(4)]
+        ck_local, gate = fill(moe, seed=3)
+        gate_t = torch.from_numpy(gate)
+        dist.broadcast(gate_t, src=0)  # the router is replicated: every rank must hold rank 0's
+        with torch.no_grad():
+            moe.gate.weight.copy_(gate_t)
+        xs = (np.random.default_rng(5).standard_normal((1, 6, 64)) * 0.5).astype(np.float16)
+        y = moe(torch.from_numpy(xs))
+        # every rank's checkpoint entries, gathered, give the whole block's reference
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ck_local)
+        ck_all = {k: v for part in gathered for k, v in part.items()}
+        want_moe = reference_block(xs.reshape(6, 64), gate_t.numpy(), ck_all, [0, 1, 2, 3], 2)
+        assert np.allclose(y.reshape(6, 64).numpy().astype(np.float32), want_moe.astype(np.float32), rtol=1e-2,
+                           atol=3e-3)
 
         ps.destroy_model_parallel()
         dist.destroy_process_group()
