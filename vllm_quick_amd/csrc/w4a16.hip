@@ -1003,7 +1003,7 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
 // (mt, t, nw, kw) of the LDS-staged kernel
 #define W4A16_FOR_EACH_TILED(X) \
   X(4, 2, 3, 4) X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
-  X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4)
+  X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4) X(1, 3, 1, 8) X(1, 1, 3, 4) X(1, 3, 1, 4) X(2, 3, 1, 8)
 
 int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1,
                    bool act = false) {
@@ -1060,10 +1060,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
-  // 17-32 rows on a very wide layer (22016 columns): the LDS-staged kernel's 2-row-tile shape shares
-  // each x slab between two waves and beats the streaming kernel by ~12 % (16.1-16.5 vs 18.3 us).
-  const bool wide_two_tiles = mtiles == 2 && (long long)NT * batch > 3 * cus && KB >= 8;
-  if (mtiles <= 2 && !wide_two_tiles) {
+  // 28-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
+  // is long or the layer wide enough to amortise their prologue (11.9 vs 13.5 us on 4096 x 11008,
+  // 20.7 vs 23.9 on 11008 x 4096; not on 4096 x 4096): x slabs arrive in whole cache lines instead of
+  // 64-byte fragments.  With fewer rows the streaming kernel's fragment loads touch fewer lines and
+  // it stays ahead.  Very wide layers (22016 columns) share each slab between two waves.
+  const bool wide = (long long)NT * batch > 3 * cus;
+  const bool two_tiles_staged = mtiles == 2 && (wide || (M >= 28 && (KB >= 64 || NT >= 512))) && KB >= 16 &&
+                                (!act || wide);  // fused activation: built for even NW only
+  if (mtiles <= 2 && !two_tiles_staged) {
     const int MT = mtiles;
     int Wv = (MT == 1) ? 16 : 8;
     while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
@@ -1099,7 +1104,10 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     if (Tt > tmax) Tt = tmax;
     return Choice{false, MT, Tt, Wv, 0};
   }
-  if (wide_two_tiles) return Choice{true, 2, 3, 2, 4};
+  if (two_tiles_staged) {
+    if (wide) return Choice{true, 2, 3, 2, 4};
+    return Choice{true, 2, 3, 1, padded_kblocks(K) % 8 == 0 ? 8 : 4};
+  }
   static const int cand[][4] = {{4, 3, 2, 4}, {4, 3, 4, 2}, {4, 3, 1, 4}, {4, 2, 2, 4},
                                 {2, 3, 2, 4}, {2, 3, 1, 4}};
   Choice best{true, 4, 3, 2, 4};
