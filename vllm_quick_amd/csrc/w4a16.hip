@@ -814,29 +814,45 @@ __global__ void __launch_bounds__(256) repack_sz_kernel(const f16* __restrict__ 
   }
 }
 
-// Dequantize from the private layout (rarely needed: M >= 256 dense path after
-// the stock tensors were dropped).  One thread per packed word.
+// Dequantize from the private layout (needed when the dense large-batch route is taken after the
+// stock tensors were dropped).  A wave takes one 128-k block of 8 adjacent column tiles: thread
+// (tile, half, octet) loads the 16-byte lane quads of 8 adjacent columns (all four k-steps of one
+// k-octet), converts them and transposes 8 columns x 8 k in registers, so that every store is
+// 16 bytes of one output row and a store instruction covers 4 rows x 256 contiguous bytes.
 __global__ void __launch_bounds__(256) dequant_packed_kernel(const uint32_t* __restrict__ pw,
                                                              const uint32_t* __restrict__ psz,
                                                              f16* __restrict__ out, int K, int N,
                                                              int G, int NT, int KB, int NG) {
-  const size_t total = (size_t)NT * KB * 256;
-  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
-       o += (size_t)gridDim.x * 256) {
-    const int j = (int)(o & 3);
-    const int l = (int)((o >> 2) & 63);
-    const size_t blk = o >> 8;
-    const int kb = (int)(blk % KB);
-    const int nt = (int)(blk / KB);
-    const int n = nt * 16 + (l & 15);
-    const int k0 = kb * 128 + j * 32 + (l >> 4) * 8;
-    if (n >= N || k0 >= K) continue;
-    const int g = k0 / G;
-    const SZ c = expand_sz(psz[((size_t)nt * NG + g) * 16 + (l & 15)]);
-    const f16x8 v = dequant_word(pw[o], c);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ntg = blockIdx.x;                 // group of 8 column tiles
+  const int o = lane >> 4;                    // k-octet of a 32-k step: 16 adjacent lanes share a row
+  const int h = lane & 1;                     // which 8 of the tile's 16 columns
+  const int nt = ntg * 8 + ((lane >> 1) & 7);
+  const int n0 = nt * 16 + h * 8;
+  if (nt >= NT || n0 >= N) return;
+  const u32x4* blocks = reinterpret_cast<const u32x4*>(pw) + (size_t)nt * KB * 64 + (o * 16 + h * 8);
+  const uint32_t* sz = psz + (size_t)nt * NG * 16 + h * 8;
+  for (int kb = blockIdx.y * 4 + wave; kb < KB; kb += gridDim.y * 4) {
+    const int kbase = kb * 128 + o * 8;
+    if (kb * 128 >= K) break;
+    u32x4 q[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (k0 + i < K) out[(size_t)(k0 + i) * N + n] = v[i];
+    for (int c = 0; c < 8; ++c) q[c] = blocks[(size_t)kb * 64 + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = kbase + j * 32;
+      if (k0 >= K) break;
+      const int g = k0 / G;
+      f16x8 v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = dequant_word(q[c][j], expand_sz(sz[g * 16 + c]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f16x8 row = f16x8{v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i]};
+        __builtin_nontemporal_store(row, reinterpret_cast<f16x8*>(out + (size_t)(k0 + i) * N + n0));
+      }
+    }
   }
 }
 
@@ -1334,9 +1350,13 @@ int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, voi
   if (rc) return rc;
   clear_stale_error();
   const int NT = ceil_div(N, 16), KB = padded_kblocks(K), NG = K / G;
-  const size_t total = (size_t)NT * KB * 256;
-  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  hipLaunchKernelGGL(dequant_packed_kernel, dim3(blocks), dim3(256), 0,
+  if (misaligned(packed_w) || misaligned(out)) return W4A16_E_ALIGN;
+  // x: groups of 8 column tiles; y: enough 4-wave workgroups over the k blocks for ~8 per CU
+  const int groups = ceil_div(NT, 8);
+  int ky = ceil_div(2048, groups);
+  if (ky > ceil_div(KB, 4)) ky = ceil_div(KB, 4);
+  if (ky < 1) ky = 1;
+  hipLaunchKernelGGL(dequant_packed_kernel, dim3(groups, ky), dim3(256), 0,
                      static_cast<hipStream_t>(stream), (const uint32_t*)packed_w,
                      (const uint32_t*)packed_sz, (f16*)out, K, N, G, NT, KB, NG);
   return launched();
