@@ -3,8 +3,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload: the single 4096 x 11008 group-128 W4A16 linear of the kernel-only sweep
-("configs[1]" of BASELINE.json), synthetic seeded inputs already resident in HBM.
+Workload: the single 4096 x 11008 group-128 W4A16 linear of the kernel-only sweep (the Llama-2-7B
+gate/up/down shape), synthetic seeded inputs already resident in HBM.
 One STEP = that linear applied twice to a batch of M = 128 tokens, once per tensor-parallel
 sharding of the layer over the N ranks:
   * column-parallel: every rank multiplies by its N/p output columns, no collective;
