@@ -12,13 +12,22 @@
 // small, and each lane ends up holding 4 adjacent output columns of one
 // token, which store as 8 contiguous bytes).
 //
-// One kernel template serves decode and prefill.  A workgroup owns T column
-// tiles x MT row tiles of the output over the WHOLE of K; its W wavefronts
-// split K between them (wave w takes 128-k blocks w, w+W, ...), stream their
-// weight blocks HBM -> VGPR with 16-byte loads, dequantise in registers
-// (bit-exactly the reference's fp16((q - z) * s)), feed the matrix cores, and
-// combine their fp32 partial tiles through LDS at the end.  There is no
-// cross-workgroup split-K, hence no workspace, no atomics and a result that
+// Two GEMM kernels share that layout and the bit-exact register conversion
+// (fp16((q - z) * s), as the reference computes it):
+//
+//  * gemm_packed_kernel ("streaming", up to 32 rows): a workgroup owns T column
+//    tiles x MT row tiles of the output over the WHOLE of K; its W wavefronts
+//    split K between them (wave w takes 128-k blocks w, w+W, ...), stream their
+//    weight blocks HBM -> VGPR with 16-byte loads, read the activation fragments
+//    straight from L2, and combine their fp32 partial tiles through LDS at the end.
+//  * gemm_tiled_kernel ("LDS-staged", more rows): the same K split, but the
+//    activation slab of each 128-k block is fetched once per workgroup in whole
+//    cache lines and shared through swizzled LDS by the waves that split the
+//    workgroup's columns.
+//
+// Both take a batch of same-shaped problems in one launch (blockIdx.z) and an
+// optional fused silu(gate) * up epilogue for merged gate/up weights.  There is
+// no cross-workgroup split-K, hence no workspace, no atomics and a result that
 // does not depend on dispatch order.
 //
 // Reference behaviour replaced: csrc/quantization/awq/gemm_kernels.cu:30-272
