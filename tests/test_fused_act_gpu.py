@@ -121,3 +121,34 @@ def test_fused_act_batched_and_errors(L, ops, cuda):
     assert lib.w4a16_gemm_packed_f16_ex(x0.data_ptr(), 0, p, p, None, o, 0, M, K, N, G, 1, 1, 1, 3, 16, 0, None) == -5
     with pytest.raises(ValueError):
         ops.awq_gemm_packed_silu_and_mul(x0, ops.awq_repack(*[dev_t(a, cuda) for a in orc.make_inputs(1, K, 48, G, seed=1)[1:]]))
+
+
+def test_fused_and_batched_launches_replay_from_a_graph(ops, cuda):
+    """The fused-epilogue and batched entry points allocate nothing and synchronise nothing, so they
+    capture into a HIP graph (decode batches run as captured graphs in the reference,
+    vllm/worker/model_runner.py:658-737); replays must track new inputs."""
+    E, M, K, N, G = 2, 4, 256, 192, 64
+    ws = [orc.make_inputs(M, K, N, G, seed=30 + e) for e in range(E)]
+    batch = ops.awq_repack_batch([dev_t(w[1], cuda) for w in ws], [dev_t(w[2], cuda) for w in ws],
+                                 [dev_t(w[3], cuda) for w in ws])
+    x = dev_t(ws[0][0], cuda)
+    eager = (ops.awq_gemm_packed_silu_and_mul(x, batch[0]), ops.awq_gemm_packed_batched(x, batch),
+             ops.awq_gemm_packed_silu_and_mul(x, batch))
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    static_x = x.clone()
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(g, stream=stream):
+            outs = (ops.awq_gemm_packed_silu_and_mul(static_x, batch[0]), ops.awq_gemm_packed_batched(static_x, batch),
+                    ops.awq_gemm_packed_silu_and_mul(static_x, batch))
+    g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs, eager))
+    x2 = dev_t(ws[1][0], cuda)
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    again = (ops.awq_gemm_packed_silu_and_mul(x2, batch[0]), ops.awq_gemm_packed_batched(x2, batch),
+             ops.awq_gemm_packed_silu_and_mul(x2, batch))
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
