@@ -1,0 +1,99 @@
+"""Randomised parity sweep on a GPU box: random shapes, group sizes, row counts and entry points
+(default launch shapes) against the oracle.  Developer check; prints a line per failure.
+
+usage: python tests/dev/fuzz_gpu.py [seconds] [seed]
+"""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import awq_oracle as orc
+from vllm_quick_amd._C import ops
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+RT, AT = 1e-2, 1e-3
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(got, want, exact, what):
+    got = got.astype(np.float64)
+    bad = np.abs(got - want) > AT + RT * np.abs(want)
+    if bad.sum() == 0:
+        return True
+    # the reference arithmetic's own slice noise: those elements must then match the fp64 result
+    # (at most a handful: 1e-4 of the outputs, or two of a small matrix)
+    ok = bad.sum() <= max(2, 1e-4 * bad.size) and (np.abs(got - exact)[bad] <= AT + RT * np.abs(exact[bad])).all()
+    if not ok:
+        print(f"FAIL {what}: {bad.sum()} of {bad.size} outside tolerance, max|d| {np.abs(got - want).max():.3e}", flush=True)
+    return ok
+
+
+t0, n, fails = time.time(), 0, 0
+while time.time() - t0 < budget:
+    G = int(rng.choice([32, 64, 128, 256]))
+    K = G * int(rng.integers(1, 24))
+    N = 8 * int(rng.integers(1, 120))
+    M = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 200, 300]))
+    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched"])
+    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
+    what = f"{mode} M={M} K={K} N={N} G={G}"
+    try:
+        if mode == "dequant":
+            w = orc.dequantize(qw, s, qz)
+            a = ops.awq_dequantize(t(qw), t(s), t(qz), 0, 0, 0).cpu().numpy()
+            b = ops.awq_dequantize_packed(ops.awq_repack(t(qw), t(s), t(qz))).cpu().numpy()
+            ok = (a.view(np.uint16) == w.view(np.uint16)).all() and (b.view(np.uint16) == w.view(np.uint16)).all()
+            if not ok:
+                print(f"FAIL {what}: dequantise not bit-exact", flush=True)
+        elif mode in ("gemm", "stock"):
+            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
+            fn = ops.awq_gemm if mode == "gemm" else (lambda a, b, c, d, _: ops.awq_gemm_stock(a, b, c, d))
+            ok = close(fn(t(x), t(qw), t(s), t(qz), 8).float().cpu().numpy(), want, exact, what)
+        elif mode == "batched":
+            E = int(rng.integers(2, 5))
+            ws = [orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30))) for _ in range(E)]
+            shared = bool(rng.integers(2)) or (M * K) % 8 != 0
+            if (M * N) % 4:
+                continue
+            pk = ops.awq_repack_batch([t(w[1]) for w in ws], [t(w[2]) for w in ws], [t(w[3]) for w in ws])
+            xs = ws[0][0] if shared else np.stack([w[0] for w in ws])
+            y = ops.awq_gemm_packed_batched(t(xs), pk).float().cpu().numpy()
+            ok = all(close(y[e], orc.gemm_faithful(xs if shared else xs[e], *ws[e][1:]).astype(np.float64),
+                           orc.gemm_exact(xs if shared else xs[e], *ws[e][1:]), what + f" e={e}") for e in range(E))
+        else:
+            N = 32 * max(1, N // 32)
+            x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
+            what = f"{mode} M={M} K={K} N={N} G={G}"
+            y = orc.gemm_faithful(x, qw, s, qz)
+            g, u = torch.from_numpy(y[:, :N // 2]), torch.from_numpy(y[:, N // 2:])
+            want = (torch.nn.functional.silu(g.float()).half() * u).numpy().astype(np.float64)
+            gd, ud = g.numpy().astype(np.float64), u.numpy().astype(np.float64)
+            sg = gd / (1 + np.exp(-gd))
+            tol = 1.1 * np.abs(ud) * (AT + RT * np.abs(gd)) + np.abs(sg) * (AT + RT * np.abs(ud)) + 2.0**-10 * np.abs(sg * ud) + 1e-6
+            pk = ops.awq_repack(t(qw), t(s), t(qz))
+            if mode == "act":
+                got = ops.awq_gemm_packed_silu_and_mul(t(x), pk).float().cpu().numpy()
+            else:
+                if (M * (N // 2)) % 4:
+                    continue
+                pkb = ops.awq_repack_batch([t(qw)] * 2, [t(s)] * 2, [t(qz)] * 2)
+                got = ops.awq_gemm_packed_silu_and_mul(t(x), pkb).float().cpu().numpy()[1]
+            err = np.abs(got - want)
+            ok = bool((err > tol).sum() <= max(2, 1e-4 * err.size) and (err <= 4 * tol).all())
+            if not ok:
+                print(f"FAIL {what}: {(err > tol).sum()} outside tolerance", flush=True)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print(f"ERROR {what}: {type(e).__name__}: {e}", flush=True)
+    n += 1
+    fails += not ok
+    if n % 50 == 0:
+        print(f"[fuzz] {n} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"[fuzz] done: {n} cases, {fails} failures")
+sys.exit(1 if fails else 0)
