@@ -17,6 +17,16 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 RT, AT = 1e-2, 1e-3
 
 
+STREAM = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 1, 8), (1, 2, 8), (1, 3, 8), (1, 4, 8), (1, 6, 8), (1, 8, 8), (1, 1, 4),
+          (1, 2, 4), (1, 3, 4), (1, 4, 4), (2, 1, 16), (2, 1, 8), (2, 2, 8), (2, 3, 8), (2, 4, 8), (2, 6, 8), (2, 1, 4),
+          (2, 2, 4), (2, 3, 4), (4, 1, 8), (4, 2, 8), (4, 3, 8), (4, 4, 8), (4, 6, 8), (4, 1, 4), (4, 2, 4), (4, 3, 4),
+          (8, 1, 8), (8, 2, 8), (8, 3, 8), (8, 1, 4), (8, 2, 4), (8, 3, 4)]
+TILED = [(4, 2, 3, 4), (4, 3, 2, 4), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (4, 3, 4, 2), (2, 3, 2, 4), (2, 3, 1, 4),
+         (8, 3, 1, 2), (8, 3, 2, 2), (4, 6, 1, 4), (2, 6, 1, 4), (1, 3, 1, 8), (1, 1, 3, 4), (1, 3, 1, 4), (2, 3, 1, 8)]
+ACT = [(1, 2, 16, 0), (1, 2, 8, 0), (1, 4, 8, 0), (1, 6, 8, 0), (1, 8, 8, 0), (1, 2, 4, 0), (1, 4, 4, 0), (2, 2, 8, 0),
+       (2, 4, 8, 0), (2, 6, 8, 0), (2, 2, 4, 0), (4, 3, 2, 4), (4, 3, 2, 2), (4, 3, 4, 2), (2, 3, 2, 4)]
+
+
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
@@ -40,7 +50,7 @@ while time.time() - t0 < budget:
     K = G * int(rng.integers(1, 24))
     N = 8 * int(rng.integers(1, 120))
     M = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 200, 300]))
-    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched"])
+    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched", "cfg", "cfg", "act_cfg"])
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
     what = f"{mode} M={M} K={K} N={N} G={G}"
     try:
@@ -55,6 +65,17 @@ while time.time() - t0 < budget:
             want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
             fn = ops.awq_gemm if mode == "gemm" else (lambda a, b, c, d, _: ops.awq_gemm_stock(a, b, c, d))
             ok = close(fn(t(x), t(qw), t(s), t(qz), 8).float().cpu().numpy(), want, exact, what)
+        elif mode == "cfg":
+            # a forced launch shape out of the built tables (row tiles must cover M for the streaming kernel)
+            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
+            cfg = STREAM[rng.integers(len(STREAM))] if rng.integers(2) else TILED[rng.integers(len(TILED))]
+            what += f" cfg={cfg}"
+            pk = ops.awq_repack(t(qw), t(s), t(qz))
+            try:
+                y = ops.awq_gemm_packed(t(x), pk, cfg=cfg)
+            except ValueError:
+                continue  # shape/launch combination the library refuses (e.g. K blocks not divisible by kw)
+            ok = close(y.float().cpu().numpy(), want, exact, what)
         elif mode == "batched":
             E = int(rng.integers(2, 5))
             ws = [orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30))) for _ in range(E)]
@@ -79,6 +100,13 @@ while time.time() - t0 < budget:
             pk = ops.awq_repack(t(qw), t(s), t(qz))
             if mode == "act":
                 got = ops.awq_gemm_packed_silu_and_mul(t(x), pk).float().cpu().numpy()
+            elif mode == "act_cfg":
+                cfg = ACT[rng.integers(len(ACT))]
+                what += f" cfg={cfg}"
+                try:
+                    got = ops.awq_gemm_packed_silu_and_mul(t(x), pk, cfg=cfg).float().cpu().numpy()
+                except ValueError:
+                    continue
             else:
                 if (M * (N // 2)) % 4:
                     continue
