@@ -655,20 +655,15 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
   for (int i = 0; i < TM; ++i) red[((kg * NW + nw) * TM + i) * 64 + lane] = acc[i / MT][i % MT];
   __syncthreads();
   STAMP(3);
-  for (int o = w; o < HW * TM; o += NWAVES) {
+  // what happens to the finished fp32 tile `o` of this workgroup (`vu`: its up-half twin with ACT)
+  auto finish_tile = [&](int o, f32x4 v, f32x4 vu) {
     const int onw = o / TM, i = o - onw * TM;
-    f32x4 v = red[(onw * TM + i) * 64 + lane];
-#pragma unroll
-    for (int g = 1; g < KW; ++g) v += red[((g * NW + onw) * TM + i) * 64 + lane];
     const int t = i / MT, mt = i - t * MT;
     const int nt = (slice * HW + onw) * T + t;
     const int n = nt * 16 + kq * 4;
     const int m = m0 + mt * 16 + n16;
     f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
     if constexpr (ACT) {
-      f32x4 vu = red[((HW + onw) * TM + i) * 64 + lane];
-#pragma unroll
-      for (int g = 1; g < KW; ++g) vu += red[((g * NW + HW + onw) * TM + i) * 64 + lane];
       const int NH = a.N / 2;
       if (nt < NTH && m < a.M) {
         f16x4 hu = f16x4{(f16)vu.x, (f16)vu.y, (f16)vu.z, (f16)vu.w};
@@ -684,6 +679,19 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
         *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
       }
     }
+  };
+  for (int o = w; o < HW * TM; o += NWAVES) {
+    const int onw = o / TM, i = o - onw * TM;
+    f32x4 v = red[(onw * TM + i) * 64 + lane];
+#pragma unroll
+    for (int g = 1; g < KW; ++g) v += red[((g * NW + onw) * TM + i) * 64 + lane];
+    f32x4 vu = v;
+    if constexpr (ACT) {
+      vu = red[((HW + onw) * TM + i) * 64 + lane];
+#pragma unroll
+      for (int g = 1; g < KW; ++g) vu += red[((g * NW + HW + onw) * TM + i) * 64 + lane];
+    }
+    finish_tile(o, v, vu);
   }
   STAMP(4);
 }
@@ -1148,13 +1156,14 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     return Choice{true, 2, 3, 1, padded_kblocks(K) % 8 == 0 ? 8 : 4};
   }
   static const int cand[][4] = {{4, 3, 2, 4}, {4, 3, 4, 2}, {4, 3, 1, 4}, {4, 2, 2, 4},
-                                {2, 3, 2, 4}, {2, 3, 1, 4}};
+                                {2, 3, 2, 4}, {2, 3, 1, 4}, {2, 3, 1, 8}};
   Choice best{true, 4, 3, 2, 4};
   double best_cost = 1e300;
   for (const auto& c : cand) {
     const int mt = c[0], t = c[1], nw = c[2], kw = c[3];
     if (mtiles <= 4 && mt == 4 && mtiles <= 2) continue;
     if (act && (nw % 2 || t != 3)) continue;  // fused-activation instantiations: see kActTiled
+    if (padded_kblocks(K) % kw) continue;
     const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt) * batch;
     const double rounds = (double)ceil_div(ctas, cus);
     double cost = rounds * mt * t * nw;               // matrix work per workgroup
