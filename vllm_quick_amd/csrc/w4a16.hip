@@ -42,6 +42,9 @@
 #ifndef W4A16_DBG
 #define W4A16_DBG 0
 #endif
+#ifndef W4A16_DEEP_TM
+#define W4A16_DEEP_TM 1
+#endif
 
 namespace {
 
@@ -313,9 +316,36 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
     }
   };
 
-  // K loop, blocks double-buffered one block ahead.  Blocks past KB are never computed;
-  // `kb_next * 128 >= K` turns the x prefetch past the end into a re-read of k = 0.
-  {
+  // K loop.  Blocks past KB are never computed; `kb_next * 128 >= K` turns the x prefetch past the
+  // end into a re-read of k = 0.  Small tiles (one or two MFMAs per weight fragment) keep three
+  // blocks in flight ahead of the one being computed instead of one: a wave's block is only
+  // T KiB of weights, and with a long K (11008) one block ahead leaves the CU with too few bytes
+  // in flight to cover HBM latency.
+  if constexpr (XPRE && T * MT <= W4A16_DEEP_TM) {
+    Block b0, b1, b2, b3;
+    f16x8 xf[MT];
+    int kb = w;
+    if (kb < a.KB) load_block(kb, b0);
+    if (kb + W < a.KB) load_block(kb + W, b1);
+    if (kb + 2 * W < a.KB) load_block(kb + 2 * W, b2);
+    while (kb < a.KB) {
+      if (kb + 3 * W < a.KB) load_block(kb + 3 * W, b3);
+      compute_block(kb, kb + W, b0, xf);
+      kb += W;
+      if (kb >= a.KB) break;
+      if (kb + 3 * W < a.KB) load_block(kb + 3 * W, b0);
+      compute_block(kb, kb + W, b1, xf);
+      kb += W;
+      if (kb >= a.KB) break;
+      if (kb + 3 * W < a.KB) load_block(kb + 3 * W, b1);
+      compute_block(kb, kb + W, b2, xf);
+      kb += W;
+      if (kb >= a.KB) break;
+      if (kb + 3 * W < a.KB) load_block(kb + 3 * W, b2);
+      compute_block(kb, kb + W, b3, xf);
+      kb += W;
+    }
+  } else {
     Block b0, b1;
     f16x8 xf[MT];
     int kb = w;
@@ -1119,6 +1149,8 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     const int MT = mtiles;
     int Wv = (MT == 1) ? 16 : 8;
     while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
+    // one or two rows over a long K (11008): 8 waves with four blocks each in flight beat 16 (8.8 vs 9.6 us)
+    if (M <= 2 && KB >= 64 && Wv == 16) Wv = 8;
     // Many tiles (batched launches, very wide layers): workgroups run back to back on a CU, and
     // small ones, several to a CU, overlap one's loads with another's arithmetic and reduction -
     // 5.4 TB/s of weights at 1-16 rows against 3.9 for one 16-wave workgroup per CU.
