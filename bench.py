@@ -298,7 +298,8 @@ def main():
     n_local = N // p
     flops_launch = 2.0 * M * K * n_local
     out["roofline"] = {
-        "kernel": "gemm_tiled_kernel<4,3,2,4> (the M=128 launch w4a16_gemm_packed_f16 makes)",
+        "kernel": ("gemm_tiled_kernel<4,3,2,4> (the M=128 launch w4a16_gemm_packed_f16 makes)" if p == 1 else
+                   f"the M=128 launch w4a16_gemm_packed_f16 makes on this rank's [{K}, {N // p}] column shard"),
         "bound": "mfma",
         "achieved": flops_launch / col_us * 1e-6,
         "peak": PEAK_F16_TFLOPS,
