@@ -6,14 +6,17 @@ from scripts._timing import time_graph
 from bench import make_weights, make_x
 dev = torch.device("cuda:0")
 shapes = {"qkv": (4096, 12288), "o": (4096, 4096), "gate_up": (4096, 22016), "down": (11008, 4096)}
+if len(sys.argv) > 2 and sys.argv[2] == "tp":  # the shard shapes of a 4096 x 11008 layer over 2/4/8 ranks
+    shapes = {f"col{p}": (4096, 11008 // p) for p in (2, 4, 8)}
+    shapes.update({f"row{p}": (4096 // p, 11008) for p in (2, 4, 8)})
 Ms = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "32,64").split(",")]
 G = 128
 STREAM = [(2, 1, 16), (2, 1, 8), (2, 2, 8), (2, 3, 8), (2, 4, 8), (2, 6, 8), (2, 1, 4), (2, 2, 4), (2, 3, 4),
           (4, 1, 8), (4, 2, 8), (4, 3, 8), (4, 4, 8), (4, 6, 8), (4, 2, 4), (4, 3, 4)]
 TILED = [(4, 3, 2, 4), (4, 3, 4, 2), (4, 3, 1, 4), (4, 2, 2, 4), (4, 2, 3, 4), (2, 3, 2, 4), (2, 3, 1, 4), (4, 3, 2, 2),
-         (2, 6, 1, 4), (4, 6, 1, 4)]
+         (2, 6, 1, 4), (4, 6, 1, 4), (2, 3, 1, 8)]
 for name, (K, N) in shapes.items():
-    nsets = max(2, int(400e6 // (K * N // 2)) + 1)
+    nsets = min(64, max(2, int(400e6 // (K * N // 2)) + 1))
     packs = [ops.awq_repack(*make_weights(K, N, G, i, dev)) for i in range(nsets)]
     for M in Ms:
         x = make_x(M, K, 1, dev)

@@ -1186,7 +1186,7 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   // 65-128 rows on a layer of at most 256 column tiles (4096 columns): 64 x 4 = 256 workgroups of the
   // streaming kernel (2 row tiles x 4 column tiles, 8 waves) fill the chip exactly and beat the
   // LDS-staged shapes by ~10 % (13.6 vs 15.0 us on 4096 x 4096, 30.2 vs 33.3 on 11008 x 4096).
-  if (!act && mtiles > 4 && mtiles <= 8 && (long long)NT * batch <= cus && NT * batch > cus / 2 && KB >= 16)
+  if (!act && mtiles > 4 && mtiles <= 8 && (long long)NT * batch <= cus && (long long)NT * batch * 8 >= cus * 7 && KB >= 16)
     return Choice{false, 2, 4, 8, 0};
   if (two_tiles_staged) {
     if (wide) return Choice{true, 2, 3, 2, 4};
@@ -1205,7 +1205,7 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     const double rounds = (double)ceil_div(ctas, cus);
     double cost = rounds * mt * t * nw;               // matrix work per workgroup
     cost *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
-    cost *= (nw * kw == 8) ? 1.0 : 1.25;              // 4-wave workgroups: one wave per SIMD
+    cost *= (nw * kw == 8) ? 1.0 : 1.4;               // 4-wave workgroups: one wave per SIMD
     cost *= 1.0 + 0.15 / nw;                          // x slab amortised over nw waves
     if (cost < best_cost) {
       best_cost = cost;
