@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 shapes = {"qkv": (4096, 12288), "o": (4096, 4096), "gate_up": (4096, 22016), "down": (11008, 4096)}
 Ms = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,8").split(",")]
 G = 128
+if sys.argv[-1] == "70b":  # Llama-2-70B layers as one of 8 tensor-parallel ranks holds them
+    shapes = {"qkv": (8192, 1280), "o": (1024, 8192), "gate_up": (8192, 7168), "down": (3584, 8192)}
 CFG = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 1, 8), (1, 2, 8), (1, 3, 8), (1, 4, 8), (1, 6, 8), (1, 8, 8),
        (1, 1, 4), (1, 2, 4), (1, 3, 4), (1, 4, 4)]
 for name, (K, N) in shapes.items():

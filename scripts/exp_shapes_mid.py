@@ -11,6 +11,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "tp":  # the shard shapes of a 4096 x 11
     shapes.update({f"row{p}": (4096 // p, 11008) for p in (2, 4, 8)})
 Ms = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "32,64").split(",")]
 G = 128
+if sys.argv[-1] == "70b":  # Llama-2-70B layers as one of 8 tensor-parallel ranks holds them
+    shapes = {"qkv": (8192, 1280), "o": (1024, 8192), "gate_up": (8192, 7168), "down": (3584, 8192)}
 STREAM = [(2, 1, 16), (2, 1, 8), (2, 2, 8), (2, 3, 8), (2, 4, 8), (2, 6, 8), (2, 1, 4), (2, 2, 4), (2, 3, 4),
           (4, 1, 8), (4, 2, 8), (4, 3, 8), (4, 4, 8), (4, 6, 8), (4, 2, 4), (4, 3, 4)]
 TILED = [(4, 3, 2, 4), (4, 3, 4, 2), (4, 3, 1, 4), (4, 2, 2, 4), (4, 2, 3, 4), (2, 3, 2, 4), (2, 3, 1, 4), (4, 3, 2, 2),
