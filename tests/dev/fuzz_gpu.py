@@ -1,7 +1,7 @@
 """Randomised parity sweep on a GPU box: random shapes, group sizes, row counts and entry points
 (default launch shapes) against the oracle.  Developer check; prints a line per failure.
 
-usage: python tests/dev/fuzz_gpu.py [seconds] [seed]
+usage: python tests/dev/fuzz_gpu.py [seconds] [seed] [large]
 """
 import os, sys, time
 import numpy as np
@@ -14,6 +14,7 @@ from vllm_quick_amd._C import ops
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
 RT, AT = 1e-2, 1e-3
 
 
@@ -32,15 +33,19 @@ def t(a):
 
 
 def close(got, want, exact, what):
+    """The policy of tests/test_gemm_gpu.py (assert_parity): within rtol/atol of the reference-faithful
+    result, except for a few outputs where that result's own fp16 slice rounding (it grows with K and
+    |y|) exceeds the bound; those must be within the bound of the fp64 result, and overall the kernel
+    must be no further from fp64 than the reference arithmetic is."""
     got = got.astype(np.float64)
     bad = np.abs(got - want) > AT + RT * np.abs(want)
     if bad.sum() == 0:
         return True
-    # the reference arithmetic's own slice noise: those elements must then match the fp64 result
-    # (at most a handful: 1e-4 of the outputs, or two of a small matrix)
-    ok = bad.sum() <= max(2, 1e-4 * bad.size) and (np.abs(got - exact)[bad] <= AT + RT * np.abs(exact[bad])).all()
+    ok = bad.sum() <= max(2, 1e-3 * bad.size) and (np.abs(got - exact)[bad] <= AT + RT * np.abs(exact[bad])).all() \
+        and np.abs(got - exact).max() <= np.abs(want - exact).max() * 1.05 + 2.0**-11 * max(1.0, np.abs(exact).max())
     if not ok:
-        print(f"FAIL {what}: {bad.sum()} of {bad.size} outside tolerance, max|d| {np.abs(got - want).max():.3e}", flush=True)
+        print(f"FAIL {what}: {bad.sum()} of {bad.size} outside tolerance, max|d| {np.abs(got - want).max():.3e}, "
+              f"vs fp64 {np.abs(got - exact).max():.3e} (reference arithmetic {np.abs(want - exact).max():.3e})", flush=True)
     return ok
 
 
@@ -49,6 +54,9 @@ while time.time() - t0 < budget:
     G = int(rng.choice([32, 64, 128, 256]))
     K = G * int(rng.integers(1, 24))
     N = 8 * int(rng.integers(1, 120))
+    if LARGE:  # model-sized layers (fewer cases: the CPU oracle takes seconds on these)
+        G = 128
+        K, N = [(4096, 1376), (4096, 2752), (11008, 4096), (4096, 4096), (2048, 11008), (4096, 5504)][rng.integers(6)]
     M = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 200, 300]))
     mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched", "cfg", "cfg", "act_cfg"])
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
@@ -121,7 +129,7 @@ while time.time() - t0 < budget:
         print(f"ERROR {what}: {type(e).__name__}: {e}", flush=True)
     n += 1
     fails += not ok
-    if n % 50 == 0:
+    if n % (5 if LARGE else 50) == 0:
         print(f"[fuzz] {n} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
 print(f"[fuzz] done: {n} cases, {fails} failures")
 sys.exit(1 if fails else 0)
