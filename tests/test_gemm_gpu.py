@@ -44,7 +44,7 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint16)
 
 
-def assert_parity(got, faithful, exact, strict=False, what=""):
+def assert_parity(got, faithful, exact, strict=False, what="", max_frac=1e-5):
     got = got.astype(np.float64)
     f = faithful.astype(np.float64)
     e = np.asarray(exact, dtype=np.float64)
@@ -52,7 +52,7 @@ def assert_parity(got, faithful, exact, strict=False, what=""):
     if strict:
         assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} outside rtol {RTOL} / atol {ATOL}"
     else:
-        assert bad.mean() <= 1e-5, f"{what}: {bad.mean():.2e} outside rtol {RTOL} / atol {ATOL}"
+        assert bad.mean() <= max_frac, f"{what}: {bad.mean():.2e} outside rtol {RTOL} / atol {ATOL}"
         assert (np.abs(got - e)[bad] <= ATOL + RTOL * np.abs(e[bad])).all(), what
     assert np.abs(got - e).max() <= np.abs(f - e).max() * 1.05 + 2.0**-11, what
 
@@ -237,6 +237,21 @@ def test_full_size_parity(abi, cuda, full, M):
     exact = x.astype(np.float64) @ full["w"].astype(np.float64)
     y = abi.gemm_packed(dev_t(x, cuda), full["packed"]).cpu().numpy()
     assert_parity(y, faithful, exact, strict=False, what=f"full M={M}")
+
+
+@pytest.mark.parametrize("M", [1, 33])
+def test_down_proj_shape_parity(abi, cuda, M):
+    """11008 -> 4096 (Llama-2-7B down_proj): the long-K layer.  The reference arithmetic's own fp16 slice
+    rounding grows with K and |y|: here it pushes ~1e-4 of ITS outputs outside rtol/atol of the fp64
+    result, so that share (5e-4 allowed) may differ from the faithful oracle by more than the bound;
+    each such output must still be within the bound of fp64, and the kernel no further from fp64 than
+    the reference arithmetic is."""
+    K, N, G = 11008, 4096, 128
+    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=2000 + M)
+    faithful, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
+    packed = abi.repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
+    y = abi.gemm_packed(dev_t(x, cuda), packed).cpu().numpy()
+    assert_parity(y, faithful, exact, strict=False, what=f"down_proj M={M}", max_frac=5e-4)
 
 
 def test_full_size_dequantize_bit_exact(abi, full):
