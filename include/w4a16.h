@@ -113,10 +113,11 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
                           const void* bias, void* out, int M, int K, int N, int G, void* stream);
 
 /*
- * Same as w4a16_gemm_packed_f16 with an explicit launch shape, for tuning and
- * tests: mt = 16-row output tiles per workgroup (1, 2, 4 or 8), t = 16-column
- * tiles per workgroup (1..8, mt * t <= 24), waves = wavefronts per workgroup
- * (1, 2, 4, 8 or 16).  Invalid combinations return W4A16_E_SHAPE.
+ * Same as w4a16_gemm_packed_f16 with an explicit launch shape of the streaming kernel, for tuning
+ * and tests: mt = 16-row output tiles per workgroup (1, 2, 4 or 8), t = 16-column tiles per
+ * workgroup (1..8, mt * t <= 24), waves = wavefronts per workgroup (4, 8 or 16).  Only the
+ * combinations the library was built with are accepted (W4A16_FOR_EACH_CFG in w4a16.hip); others
+ * return W4A16_E_SHAPE.
  */
 int w4a16_gemm_packed_f16_cfg(const void* x, const void* packed_w, const void* packed_sz,
                               const void* bias, void* out, int M, int K, int N, int G, int mt,
