@@ -42,6 +42,9 @@
 #ifndef W4A16_DBG
 #define W4A16_DBG 0
 #endif
+#ifndef W4A16_PANEL
+#define W4A16_PANEL 4
+#endif
 #ifndef W4A16_DEEP_TM
 #define W4A16_DEEP_TM 1
 #endif
@@ -463,10 +466,10 @@ __device__ unsigned long long g_stamps[4096 * 32];
 // ACT (gate | up weight, silu(gate) * up stored, see gemm_packed_kernel): the first NW / 2 waves of a
 // K-group take the workgroup's gate columns, the others the matching up columns.
 template <int MT, int T, int NW, int KW, int SZS, bool ACT = false>
-__global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, int m_blocks,
+__global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, int m_blocks, int panel_rows,
                                                                    const GemmArgs ga) {
   fetch_args_now(ga);
-  asm volatile("" ::"s"(n_slices), "s"(m_blocks));
+  asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
   const GemmArgs a = batch_slice(ga);
   constexpr int NWAVES = NW * KW;
   constexpr int HW = ACT ? NW / 2 : NW;    // waves per half
@@ -488,11 +491,17 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
   unsigned long long t_work = 0, t_bar = 0;
 #endif
 
-  // Workgroups that share an XCD's L2 are those whose ids are equal mod 8.  Give the m_blocks
-  // row-blocks of one column slice ids 8 apart, so their weight reads meet in one L2.
+  // Workgroups that share an XCD's L2 are those whose ids are equal mod 8.  Within an XCD the
+  // (column slice, row-block) pairs are walked in panels of `panel_rows` row-blocks: slice after
+  // slice, and for each slice the panel's row-blocks next to each other, so that the ~32 workgroups
+  // an XCD runs at a time share their weight slices AND their activation rows through its L2.
+  // Up to 8 row-blocks the panel is all of them: the row-blocks of a slice get ids 8 apart.
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int slice = (idx / m_blocks) * 8 + xcd;
-  const int mb = idx % m_blocks;
+  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
+  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
+  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
+  const int slice = (in_panel / rows_here) * 8 + xcd;
+  const int mb = panel * panel_rows + in_panel % rows_here;
   if (slice >= n_slices) return;  // whole workgroup: no barrier is skipped by a subset
   const int nt0 = (slice * HW + nw % HW) * T;
   const int m0 = mb * ROWS;
@@ -1047,7 +1056,7 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   const int n_slices = act ? ceil_div(a.NT / 2, NW / 2 * T) : ceil_div(a.NT, NW * T);
   const int m_blocks = ceil_div(a.M, MT * 16);
   const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
-  void (*kern)(int, int, const GemmArgs) = nullptr;
+  void (*kern)(int, int, int, const GemmArgs) = nullptr;
   if (act) {
     if constexpr (kActTiled<MT, T, NW, KW>) {
       if (a.G % 128 == 0)
@@ -1073,7 +1082,9 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
       return W4A16_E_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW * KW), lds, s, n_slices, m_blocks, a);
+  // panels of W4A16_PANEL row-blocks once there are more than 8 of them (see the kernel's id mapping)
+  const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW * KW), lds, s, n_slices, m_blocks, panel_rows, a);
   return launched();
 }
 
@@ -1202,11 +1213,13 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     if (act && (nw % 2 || t != 3)) continue;  // fused-activation instantiations: see kActTiled
     if (padded_kblocks(K) % kw) continue;
     const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt) * batch;
-    const double rounds = (double)ceil_div(ctas, cus);
+    // whole rounds of workgroups while they are few; with many rounds the partial last one fades
+    const double rounds = ctas > 2 * cus ? (double)ctas / cus + 0.5 : (double)ceil_div(ctas, cus);
     double cost = rounds * mt * t * nw;               // matrix work per workgroup
     cost *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
+    cost *= (t == 3) ? 1.0 : 1.15;                    // x fragments re-used by 2 instead of 3 column tiles
     cost *= (nw * kw == 8) ? 1.0 : 1.4;               // 4-wave workgroups: one wave per SIMD
-    cost *= 1.0 + 0.15 / nw;                          // x slab amortised over nw waves
+    cost *= 1.0 + 0.6 / nw;                           // x slab staged once per nw column waves
     if (cost < best_cost) {
       best_cost = cost;
       best = Choice{true, mt, t, nw, kw};
