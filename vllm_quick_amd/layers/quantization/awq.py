@@ -78,8 +78,8 @@ class AWQLinearMethod(LinearMethodBase):
             weights to HBM and calls `torch.matmul`, the reference's large-batch route
             (awq.py:154-159).  The reference switches at 256 tokens, a heuristic tuned to its
             CUDA kernel; on MI355X the fused kernel stays ahead of dequantise + hipBLASLt up to
-            about a thousand tokens on Llama-2 shapes (2.2x at 256, 1.4x at 512, level at 1024,
-            behind from 2048), so the default here is 1024.  Pass 256 for the reference's exact
+            about a thousand tokens on Llama-2 shapes (2.2x at 256, 1.4x at 512, level between
+            1024 and 2048, behind at 4096), so the default here is 1024.  Pass 256 for the reference's exact
             operator choice, `None` to always use the fused kernel.
     """
 
