@@ -1,0 +1,147 @@
+// A host program with no PyTorch in it: drives libw4a16.so through include/w4a16.h with plain HIP
+// allocations, the way a C/C++ caller of the reference's operators would, and checks the results
+// against the C restatement of the reference arithmetic (oracle/awq_oracle.c - the checker; this
+// program is test infrastructure, built by __graft_entry__.build() and run by tests/test_native_gpu.py).
+//
+//   c_abi_check            -> prints one line per check and exits 0 if all pass
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "w4a16.h"
+
+extern "C" {
+void awq_c_dequantize(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros, uint16_t* out, int K,
+                      int N, int G);
+int awq_c_gemm(const uint16_t* x, const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+               uint16_t* out, int M, int K, int N, int G, int split_k, int faithful);
+uint16_t awq_c_f2h(float f);
+float awq_c_h2f(uint16_t h);
+}
+
+#define HIP_OK(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      std::fprintf(stderr, "%s failed: %s\n", #call, hipGetErrorString(e_));           \
+      std::exit(2);                                                                    \
+    }                                                                                  \
+  } while (0)
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() {  // xorshift64*
+  rng_state ^= rng_state >> 12;
+  rng_state ^= rng_state << 25;
+  rng_state ^= rng_state >> 27;
+  return (uint32_t)((rng_state * 0x2545f4914f6cdd1dull) >> 32);
+}
+static float uniform() { return (rnd() >> 8) * (1.0f / 16777216.0f); }
+static float normal() {
+  const float u1 = uniform() + 1e-7f, u2 = uniform();
+  return std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2);
+}
+
+template <typename T>
+static T* to_device(const std::vector<T>& h) {
+  T* d = nullptr;
+  HIP_OK(hipMalloc(&d, h.size() * sizeof(T)));
+  HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+static int check_case(int M, int K, int N, int G, bool with_bias) {
+  std::vector<int32_t> qw((size_t)K * N / 8), qz((size_t)(K / G) * N / 8);
+  std::vector<uint16_t> sc((size_t)(K / G) * N), x((size_t)M * K), bias(N);
+  for (auto& v : qw) v = (int32_t)rnd();
+  for (auto& v : qz) v = (int32_t)rnd();
+  for (auto& v : sc) v = awq_c_f2h(1e-3f + uniform() * 1.9e-2f);
+  for (auto& v : x) v = awq_c_f2h(normal() * 0.25f);
+  for (auto& v : bias) v = awq_c_f2h(normal() * 0.1f);
+
+  int32_t *d_qw = to_device(qw), *d_qz = to_device(qz);
+  uint16_t *d_sc = to_device(sc), *d_x = to_device(x), *d_bias = to_device(bias);
+  void *d_pw = nullptr, *d_ps = nullptr;
+  uint16_t *d_out = nullptr, *d_deq = nullptr;
+  HIP_OK(hipMalloc(&d_pw, w4a16_packed_weight_bytes(K, N)));
+  HIP_OK(hipMalloc(&d_ps, w4a16_packed_sz_bytes(K, N, G)));
+  HIP_OK(hipMalloc(&d_out, (size_t)M * N * 2));
+  HIP_OK(hipMalloc(&d_deq, (size_t)K * N * 2));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+
+  int fails = 0;
+  auto expect_ok = [&](int rc, const char* what) {
+    if (rc != W4A16_OK) {
+      std::printf("FAIL %s: %s (hip error %d)\n", what, w4a16_strerror(rc), w4a16_last_hip_error());
+      ++fails;
+    }
+  };
+  // oracle results
+  std::vector<uint16_t> want_deq((size_t)K * N), want((size_t)M * N), got((size_t)M * N), got_deq((size_t)K * N);
+  awq_c_dequantize(qw.data(), sc.data(), qz.data(), want_deq.data(), K, N, G);
+  if (awq_c_gemm(x.data(), qw.data(), sc.data(), qz.data(), want.data(), M, K, N, G, 8, 1) != 0) return 1;
+
+  auto compare = [&](const char* what, bool add_bias) {
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(got.data(), d_out, got.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    double worst = 0;
+    for (size_t i = 0; i < got.size(); ++i) {
+      double w = awq_c_h2f(want[i]);
+      if (add_bias) w = awq_c_h2f(awq_c_f2h((float)w + awq_c_h2f(bias[i % N])));
+      const double d = std::fabs((double)awq_c_h2f(got[i]) - w);
+      worst = d > worst ? d : worst;
+      if (d > 1e-3 * (add_bias ? 2 : 1) + 1e-2 * std::fabs(w)) ++bad;  // rtol 1e-2 / atol 1e-3 (2e-3 with the fp16 bias add)
+    }
+    std::printf("%s %s M=%d K=%d N=%d G=%d: %zu of %zu outside tolerance, max |d| %.3e\n", bad ? "FAIL" : "ok  ",
+                what, M, K, N, G, bad, got.size(), worst);
+    fails += bad != 0;
+  };
+
+  expect_ok(w4a16_gemm_f16(d_x, d_qw, d_sc, d_qz, d_out, M, K, N, G, 8, stream), "w4a16_gemm_f16");
+  compare("gemm (stock layout)   ", false);
+  expect_ok(w4a16_repack(d_qw, d_sc, d_qz, d_pw, d_ps, K, N, G, stream), "w4a16_repack");
+  HIP_OK(hipMemsetAsync(d_out, 0xff, (size_t)M * N * 2, stream));
+  expect_ok(w4a16_gemm_packed_f16(d_x, d_pw, d_ps, with_bias ? d_bias : nullptr, d_out, M, K, N, G, stream),
+            "w4a16_gemm_packed_f16");
+  compare(with_bias ? "gemm (packed) + bias  " : "gemm (packed)         ", with_bias);
+
+  for (int packed = 0; packed < 2; ++packed) {
+    expect_ok(packed ? w4a16_dequantize_packed_f16(d_pw, d_ps, d_deq, K, N, G, stream)
+                     : w4a16_dequantize_f16(d_qw, d_sc, d_qz, d_deq, K, N, G, stream),
+              "dequantize");
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(got_deq.data(), d_deq, got_deq.size() * 2, hipMemcpyDeviceToHost));
+    size_t diff = 0;
+    for (size_t i = 0; i < got_deq.size(); ++i) diff += got_deq[i] != want_deq[i];
+    std::printf("%s dequantize (%s) K=%d N=%d G=%d: %zu words differ (must be bit-exact)\n", diff ? "FAIL" : "ok  ",
+                packed ? "packed" : "stock ", K, N, G, diff);
+    fails += diff != 0;
+  }
+  // argument errors come back as codes, nothing is launched
+  if (w4a16_gemm_f16(d_x, d_qw, d_sc, d_qz, d_out, M, K, N + 4, G, 8, stream) != W4A16_E_OC_PACK) ++fails;
+  if (w4a16_gemm_packed_f16(nullptr, d_pw, d_ps, nullptr, d_out, M, K, N, G, stream) != W4A16_E_NULL) ++fails;
+
+  HIP_OK(hipStreamDestroy(stream));
+  for (void* p : {(void*)d_qw, (void*)d_qz, (void*)d_sc, (void*)d_x, (void*)d_bias, d_pw, d_ps, (void*)d_out, (void*)d_deq})
+    HIP_OK(hipFree(p));
+  return fails;
+}
+
+int main() {
+  if (w4a16_abi_version() != W4A16_ABI_VERSION) {
+    std::printf("FAIL ABI version %d, header says %d\n", w4a16_abi_version(), W4A16_ABI_VERSION);
+    return 1;
+  }
+  int fails = 0;
+  fails += check_case(1, 512, 256, 128, false);
+  fails += check_case(7, 384, 200, 64, true);
+  fails += check_case(40, 640, 416, 32, false);
+  fails += check_case(130, 1024, 1376, 128, true);
+  std::printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
+  return fails ? 1 : 0;
+}
