@@ -54,6 +54,24 @@ def fill_awq(layer, gen, device):
     s.data = (torch.rand(s.shape, generator=gen, device=device) * (2e-2 - 1e-3) + 1e-3).half() * 0.1
 
 
+def rms_norm(x, w, eps=1e-5):
+    """RMSNorm with fp32 statistics, one fused op."""
+    return F.rms_norm(x, (x.shape[-1], ), w, eps)
+
+
+def rope_tables(cos, sin):
+    """Full-width tables for `rope_neox` from the half-width ones: [cos, cos] and [-sin, sin]."""
+    return torch.cat([cos, cos], -1), torch.cat([-sin, sin], -1)
+
+
+def rope_neox(t, cos2, sin2):
+    """GPT-NeoX style rotary embedding, (t1, t2) -> (t1 cos - t2 sin, t2 cos + t1 sin), as
+    t * [cos, cos] + swap_halves(t) * [-sin, sin]: three elementwise launches for all heads."""
+    half = t.shape[-1] // 2
+    swapped = torch.cat([t[..., half:], t[..., :half]], -1)
+    return torch.addcmul(t * cos2, swapped, sin2)
+
+
 class DecoderLayer(torch.nn.Module):
 
     def __init__(self, cfg, method, max_bs, max_len, device):
@@ -78,30 +96,21 @@ class DecoderLayer(torch.nn.Module):
 
     @staticmethod
     def rms(x, w):
-        v = x.float()
-        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).half() * w
+        return rms_norm(x, w)
 
     def forward(self, x, pos, cos, sin, ctx_len):
         bs = x.shape[0]
         hdn = self.rms(x, self.ln1)
         qkv, _ = self.qkv_proj(hdn)
-        q, k, v = qkv.split([self.n_heads * self.head_dim, self.n_kv * self.head_dim, self.n_kv * self.head_dim], -1)
-        q = q.view(bs, self.n_heads, 1, self.head_dim)
-        k = k.view(bs, self.n_kv, 1, self.head_dim)
-        v = v.view(bs, self.n_kv, 1, self.head_dim)
-
-        def rope(t):
-            t1, t2 = t[..., :self.head_dim // 2], t[..., self.head_dim // 2:]
-            return torch.cat([t1 * cos - t2 * sin, t2 * cos + t1 * sin], -1)
-
-        q, k = rope(q), rope(k)
+        nq, nkv, hd = self.n_heads, self.n_kv, self.head_dim
+        # rotary embedding on the query and key heads in one pass (they are adjacent in the qkv output)
+        qk = rope_neox(qkv[:, :(nq + nkv) * hd].view(bs, nq + nkv, 1, hd), cos, sin)
+        q, k = qk[:, :nq], qk[:, nq:]
+        v = qkv[:, (nq + nkv) * hd:].view(bs, nkv, 1, hd)
         self.k_cache[:bs, :, pos:pos + 1] = k
         self.v_cache[:bs, :, pos:pos + 1] = v
         kk, vv = self.k_cache[:bs, :, :ctx_len], self.v_cache[:bs, :, :ctx_len]
-        if self.n_kv != self.n_heads:
-            rep = self.n_heads // self.n_kv
-            kk, vv = kk.repeat_interleave(rep, 1), vv.repeat_interleave(rep, 1)
-        att = F.scaled_dot_product_attention(q, kk, vv)
+        att = F.scaled_dot_product_attention(q, kk, vv, enable_gqa=self.n_kv != self.n_heads)
         o, _ = self.o_proj(att.reshape(bs, -1))
         x = x + o
         hdn = self.rms(x, self.ln2)
@@ -152,7 +161,7 @@ class Model(torch.nn.Module):
 
     def step(self, tokens, pos, ctx_len):
         x = self.embed[tokens]
-        cos, sin = self.cos[pos], self.sin[pos]
+        cos, sin = rope_tables(self.cos[pos], self.sin[pos])
         for layer in self.layers:
             x = layer(x, pos, cos, sin, ctx_len)
         x = DecoderLayer.rms(x, self.norm)
