@@ -1,22 +1,28 @@
 """Collectives of the tensor-parallel linear layers.
 
-Reference: vllm/model_executor/parallel_utils/communication_op.py:17-69.  The
-reference tries a CUDA-IPC custom kernel, then CuPy-NCCL, then
-torch.distributed; on MI355X the path is torch.distributed over RCCL, whose
-ring/tree/direct choice already fits the point-to-point xGMI mesh.
+Reference: vllm/model_executor/parallel_utils/communication_op.py:17-69.  As there, an all-reduce
+first tries the one-kernel peer-to-peer path (`custom_all_reduce`, active once `init_custom_ar()`
+has run for the group and for inputs it accepts) and otherwise goes to torch.distributed: RCCL
+over xGMI on GPUs, gloo in CPU tests.  (The reference's CuPy-NCCL leg exists only to make NCCL
+capturable in CUDA graphs and has no counterpart.)
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
+from .custom_all_reduce import custom_all_reduce
 from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_parallel_world_size)
 
 
 def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
-    """Sum over the TP group.  In place; callers must still use the return value."""
+    """Sum over the TP group.  May or may not work in place: always assume the input is modified
+    and use the return value (communication_op.py:17-41)."""
     if get_tensor_model_parallel_world_size() == 1:
         return input_
+    out = custom_all_reduce(input_)
+    if out is not None:
+        return out
     dist.all_reduce(input_, group=get_tensor_model_parallel_group())
     return input_
 
