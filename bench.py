@@ -139,6 +139,37 @@ def load_traffic():
     return {}
 
 
+def p2p_all_reduce_section(backend, rank, world):
+    """The one-kernel peer-to-peer all-reduce against the collective library on this node's GPUs:
+    correctness flags and latencies per message size (benchmarks/allreduce_bench.py).  It runs in
+    child processes, one per rank with a process group of their own, so that nothing it does can
+    disturb the figures measured above; a failure is reported in the result, not raised."""
+    import socket
+    import subprocess
+    port = [0]
+    if rank == 0:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port[0] = sock.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    # a rendezvous of the children's own: not the launcher's store
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    cmd = [sys.executable, os.path.join(ROOT, "benchmarks", "allreduce_bench.py"), "--backend", backend]
+    if torch.cuda.device_count() < world:
+        cmd.append("--same-device")
+    res = {"ok": False}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if rank == 0:
+            res = json.loads(lines[-1]) if lines else {"ok": False, "error": f"exit {r.returncode}: {r.stderr[-400:]}"}
+    except Exception as e:  # noqa: BLE001 - a measurement aid must not take the benchmark down
+        res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    dist.barrier()
+    return res if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +178,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the Llama-2-7B-shaped decode harness and the Mixtral-shaped experts block")
+    ap.add_argument("--no-p2p", action="store_true", help="N > 1: skip the peer-to-peer all-reduce comparison (child processes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
     args = ap.parse_args()
 
@@ -283,6 +315,10 @@ def main():
         tp["all_reduce_us"] = e0.elapsed_time(e1) * 1e3 / 64
         tp["all_reduce_bytes"] = 2 * M * N
 
+    p2p = None
+    if world > 1 and not args.no_p2p:
+        p2p = p2p_all_reduce_section(args.backend, rank, world)
+
     out = {
         "metric": "W4A16 GEMM TFLOPS (4096x11008 g128, M=128)",
         "value": value,
@@ -304,6 +340,8 @@ def main():
         },
         "tp": tp,
     }
+    if p2p is not None:
+        out["p2p_all_reduce"] = p2p
 
     # roofline of the dominant kernel of the timed region: the M=128 GEMM on this rank's column shard
     # (at N=1 the whole layer).  Algorithmic flops per launch / mean launch duration.

@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=128)
     ap.add_argument("--no-fuse-act", action="store_true", help="run gate_up GEMM and silu-and-mul as separate ops")
+    ap.add_argument("--p2p-all-reduce", action="store_true",
+                    help="tensor parallel: the one-kernel peer-to-peer all-reduce instead of RCCL")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -239,9 +241,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         ps.initialize_model_parallel(world)
+        if a.p2p_all_reduce:
+            from vllm_quick_amd.parallel_utils import custom_all_reduce as car
+            car.init_custom_ar()
     t0 = time.time()
     out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx, fuse_act=not a.no_fuse_act)
     out["wall_s"] = time.time() - t0
+    out["all_reduce"] = "peer-to-peer kernel" if world > 1 and a.p2p_all_reduce else ("rccl" if world > 1 else None)
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(out))
     if world > 1:
