@@ -12,6 +12,8 @@ benchmarks/benchmark_latency.py:59-65).
 
     python benchmarks/llama_decode.py [--model 7b|70b] [--bs 1,2,4,8,16,32,64] [--layers N]
     torchrun --nproc-per-node 8 benchmarks/llama_decode.py --model 70b      # tensor parallel
+    torchrun --nproc-per-node 2 benchmarks/llama_decode.py --backend gloo --same-device --p2p-all-reduce
+                                                                            # rehearsal on one GPU
 """
 from __future__ import annotations
 
@@ -231,15 +233,21 @@ def main():
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=128)
     ap.add_argument("--no-fuse-act", action="store_true", help="run gate_up GEMM and silu-and-mul as separate ops")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL), or gloo for a "
+                    "rehearsal (then every all-reduce must take the peer-to-peer path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--p2p-all-reduce", action="store_true",
                     help="tensor parallel: the one-kernel peer-to-peer all-reduce instead of RCCL")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    local = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
         ps.initialize_model_parallel(world)
         if a.p2p_all_reduce:
             from vllm_quick_amd.parallel_utils import custom_all_reduce as car
@@ -248,6 +256,10 @@ def main():
     out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx, fuse_act=not a.no_fuse_act)
     out["wall_s"] = time.time() - t0
     out["all_reduce"] = "peer-to-peer kernel" if world > 1 and a.p2p_all_reduce else ("rccl" if world > 1 else None)
+    if world > 1 and a.p2p_all_reduce:
+        from vllm_quick_amd.parallel_utils import custom_all_reduce as car
+        out["all_reduce_timed_out"] = car.get_handle().timed_out() if car.get_handle() is not None else None
+        car.destroy_custom_ar()
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(out))
     if world > 1:

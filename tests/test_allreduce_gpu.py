@@ -157,6 +157,31 @@ def _worker(rank, world, port, q):
             torch.cuda.synchronize()
             del graph
 
+        # the caller this exists for: a row-parallel W4A16 linear, partial products summed over the ranks
+        # (vllm/model_executor/layers/linear.py:541-542)
+        if world in (2, 4):
+            from oracle import awq_oracle as orc
+            from vllm_quick_amd.layers import linear as L
+            from vllm_quick_amd.layers.quantization import AWQConfig
+            method = AWQConfig(4, 32, True).get_linear_method()
+            M, K, N = 5, 256, 192
+            xh, qw, sc, qz = orc.make_inputs(M, K, N, 32, seed=41)
+            want = orc.gemm_faithful(xh, qw, sc, qz).astype(np.float32)
+            row = L.RowParallelLinear(K, N, bias=False, input_is_parallel=False, params_dtype=torch.float16,
+                                      linear_method=method).to(dev)
+            for name, arr in (("qweight", qw), ("scales", sc), ("qzeros", qz)):
+                prm = getattr(row, name)
+                prm.weight_loader(prm, torch.from_numpy(arr))
+            calls = []
+            inner = fa.all_reduce_unreg
+            fa.all_reduce_unreg = lambda t, out=None: (calls.append(t.shape), inner(t, out))[1]
+            y, _ = row(torch.from_numpy(xh).to(dev))
+            fa.all_reduce_unreg = inner
+            assert calls == [(M, N)], "the layer's all-reduce did not take the peer-to-peer path"
+            # tolerance of the W4A16 GEMM parity tests: rtol 1e-2, atol 1e-3 (+1e-3 for the extra fp16 rounding
+            # of each rank's partial product)
+            assert np.allclose(y.float().cpu().numpy(), want, rtol=1e-2, atol=2e-3)
+
         assert not fa.timed_out(), "a kernel gave up waiting for a peer"
         car.destroy_custom_ar()
         ps.destroy_model_parallel()
