@@ -139,11 +139,11 @@ def load_traffic():
     return {}
 
 
-def p2p_all_reduce_section(backend, rank, world):
-    """The one-kernel peer-to-peer all-reduce against the collective library on this node's GPUs:
-    correctness flags and latencies per message size (benchmarks/allreduce_bench.py).  It runs in
-    child processes, one per rank with a process group of their own, so that nothing it does can
-    disturb the figures measured above; a failure is reported in the result, not raised."""
+def run_children(script, script_args, rank, world, timeout_s=180):
+    """Runs `script` once per rank in child processes that form a process group of their own (same
+    RANK / LOCAL_RANK / WORLD_SIZE, a fresh rendezvous port), so that nothing they do can disturb the
+    figures measured in this process; returns rank 0's JSON line.  A failure is reported in the
+    result, not raised."""
     import socket
     import subprocess
     port = [0]
@@ -155,18 +155,36 @@ def p2p_all_reduce_section(backend, rank, world):
     # a rendezvous of the children's own: not the launcher's store
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
-    cmd = [sys.executable, os.path.join(ROOT, "benchmarks", "allreduce_bench.py"), "--backend", backend]
+    cmd = [sys.executable, os.path.join(ROOT, script)] + list(script_args)
     if torch.cuda.device_count() < world:
         cmd.append("--same-device")
     res = {"ok": False}
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if rank == 0:
             res = json.loads(lines[-1]) if lines else {"ok": False, "error": f"exit {r.returncode}: {r.stderr[-400:]}"}
     except Exception as e:  # noqa: BLE001 - a measurement aid must not take the benchmark down
         res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     dist.barrier()
+    return res if rank == 0 else None
+
+
+def p2p_all_reduce_section(backend, rank, world):
+    """The one-kernel peer-to-peer all-reduce against the collective library on this node's GPUs:
+    correctness flags and latencies per message size (benchmarks/allreduce_bench.py)."""
+    return run_children(os.path.join("benchmarks", "allreduce_bench.py"), ["--backend", backend], rank, world)
+
+
+def decode_tp_section(backend, rank, world):
+    """Tensor-parallel half of the headline metric: Llama-2-70B-AWQ-shaped greedy decode over `world`
+    ranks (8 of the 80 layers run, extrapolated), with RCCL and with the peer-to-peer all-reduce.
+    (Llama-2-7B's 11008-wide down_proj cannot be row-split 4 or 8 ways at group 128.)"""
+    base = ["--model", "70b", "--layers", "8", "--bs", "1,8,64", "--backend", backend]
+    res = {}
+    if backend == "nccl":
+        res["rccl"] = run_children(os.path.join("benchmarks", "llama_decode.py"), base, rank, world)
+    res["p2p"] = run_children(os.path.join("benchmarks", "llama_decode.py"), base + ["--p2p-all-reduce"], rank, world)
     return res if rank == 0 else None
 
 
@@ -315,9 +333,11 @@ def main():
         tp["all_reduce_us"] = e0.elapsed_time(e1) * 1e3 / 64
         tp["all_reduce_bytes"] = 2 * M * N
 
-    p2p = None
+    p2p = decode_tp = None
     if world > 1 and not args.no_p2p:
         p2p = p2p_all_reduce_section(args.backend, rank, world)
+    if world > 1 and not args.no_decode:
+        decode_tp = decode_tp_section(args.backend, rank, world)
 
     out = {
         "metric": "W4A16 GEMM TFLOPS (4096x11008 g128, M=128)",
@@ -342,6 +362,8 @@ def main():
     }
     if p2p is not None:
         out["p2p_all_reduce"] = p2p
+    if decode_tp is not None:
+        out["decode_tp"] = decode_tp
 
     # roofline of the dominant kernel of the timed region: the M=128 GEMM on this rank's column shard
     # (at N=1 the whole layer).  Algorithmic flops per launch / mean launch duration.
