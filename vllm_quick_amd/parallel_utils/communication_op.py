@@ -3,8 +3,8 @@
 Reference: vllm/model_executor/parallel_utils/communication_op.py:17-69.  As there, an all-reduce
 first tries the one-kernel peer-to-peer path (`custom_all_reduce`, active once `init_custom_ar()`
 has run for the group and for inputs it accepts) and otherwise goes to torch.distributed: RCCL
-over xGMI on GPUs, gloo in CPU tests.  (The reference's CuPy-NCCL leg exists only to make NCCL
-capturable in CUDA graphs and has no counterpart.)
+over xGMI on GPUs, gloo in CPU tests.  Inside `with_rccl_for_all_reduce()` (graph capture) RCCL is
+called directly (`rccl_utils`), the counterpart of the reference's CuPy-NCCL leg.
 """
 from __future__ import annotations
 
@@ -12,7 +12,9 @@ import torch
 import torch.distributed as dist
 
 from .custom_all_reduce import custom_all_reduce
-from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_parallel_world_size)
+from . import rccl_utils
+from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_parallel_world_size,
+                             is_rccl_enabled_for_all_reduce)
 
 
 def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
@@ -23,7 +25,10 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     out = custom_all_reduce(input_)
     if out is not None:
         return out
-    dist.all_reduce(input_, group=get_tensor_model_parallel_group())
+    if is_rccl_enabled_for_all_reduce():
+        rccl_utils.all_reduce(input_)  # capturable: no helper thread watches it
+    else:
+        dist.all_reduce(input_, group=get_tensor_model_parallel_group())
     return input_
 
 

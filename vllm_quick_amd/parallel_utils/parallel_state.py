@@ -9,6 +9,7 @@ same accessor names.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import torch.distributed as dist
@@ -69,3 +70,36 @@ def destroy_model_parallel() -> None:
     if _TP_GROUP is not None and dist.is_initialized():
         dist.destroy_process_group(_TP_GROUP)
     _TP_GROUP, _TP_RANKS = None, None
+    from . import rccl_utils
+    rccl_utils.destroy_process_group()  # the direct communicator, if any (parallel_state.py:213-214)
+
+
+# Whether all-reduces go to RCCL directly instead of through torch.distributed: needed while a
+# HIP graph is captured, where ProcessGroupNCCL's watchdog aborts the process
+# (parallel_state.py:217-245 does the same with CuPy's NCCL binding, for the same reason).
+_ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE = False
+
+
+@contextlib.contextmanager
+def with_rccl_for_all_reduce():
+    """Use the direct RCCL communicator (rccl_utils) for all-reduce inside this block; each call
+    goes to the stream that is current when it is made (the capturing stream, under capture)."""
+    global _ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE
+    if get_tensor_model_parallel_world_size() == 1:
+        yield  # nothing to reduce; the communicator is not even created
+        return
+    old = _ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE
+    _ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE = True
+    try:
+        yield
+    finally:
+        _ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE = old
+
+
+def is_rccl_enabled_for_all_reduce() -> bool:
+    return _ENABLE_DIRECT_RCCL_FOR_ALL_REDUCE
+
+
+# the reference's names, so that its call sites (vllm/worker/model_runner.py capture loop) read the same
+with_cupy_nccl_for_all_reduce = with_rccl_for_all_reduce
+is_cupy_nccl_enabled_for_all_reduce = is_rccl_enabled_for_all_reduce
