@@ -76,7 +76,9 @@ def graph_of(fns, stream):
             f()
         stream.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        # thread-local capture mode: a process group's helper threads may call the runtime meanwhile
+        mode = "thread_local" if dist.is_initialized() else "global"
+        with torch.cuda.graph(g, stream=stream, capture_error_mode=mode):
             for f in fns:
                 f()
     return g
@@ -245,8 +247,41 @@ def main():
     stream = torch.cuda.Stream(device=device)
     group = dist.group.WORLD if world > 1 else None
 
+    # The collective of the step.  With RCCL it is called directly (rccl_utils), so that the whole step
+    # can be captured in a HIP graph like the N=1 step (torch.distributed's RCCL path cannot be captured:
+    # its watchdog thread aborts the process); if that set-up fails, torch.distributed launched eagerly.
+    collective = "torch.distributed, launched eagerly"
+    direct = None
+    if world > 1 and args.backend == "nccl":
+        try:
+            import socket
+            from vllm_quick_amd.parallel_utils import rccl_utils
+            port = [0]
+            if rank == 0:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    port[0] = sock.getsockname()[1]
+            dist.broadcast_object_list(port, src=0)
+            rccl_utils.init_process_group(world, rank, "127.0.0.1", port[0])
+            probe = torch.full((1024, ), float(rank + 1), dtype=torch.float16, device=device)
+            rccl_utils.all_reduce(probe)
+            torch.cuda.synchronize()
+            if not bool((probe == world * (world + 1) / 2).all()):
+                raise RuntimeError("direct RCCL all-reduce returned a wrong sum")
+            direct = rccl_utils
+            collective = "RCCL called directly, step replayed from a HIP graph"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] direct RCCL communicator unavailable ({e}); eager torch.distributed", file=sys.stderr,
+                  flush=True)
+        flags = [None] * world
+        dist.all_gather_object(flags, direct is not None)
+        if not all(flags):
+            direct, collective = None, "torch.distributed, launched eagerly"
+
     def all_reduce(y):
-        if args.backend == "nccl":
+        if direct is not None:
+            direct.all_reduce(y)  # in place, on the current stream
+        elif args.backend == "nccl":
             dist.all_reduce(y, group=group)  # RCCL, in place, ordered after the GEMM on this stream
         else:  # rehearsal backends (gloo): reduce a host copy
             h = y.cpu()
@@ -275,11 +310,17 @@ def main():
 
     # ---- timed region: exactly `steps` steps, barrier + synchronize on both sides ----------
     # On one GPU the steps are replayed from a HIP graph (NBUF steps per replay, the remainder
-    # launched directly) so that host launch cost cannot bound a ~10 us kernel; with a collective
-    # in the step they are launched directly.
+    # launched directly) so that host launch cost cannot bound a ~10 us kernel; so are the steps with
+    # the directly called RCCL all-reduce in them.  Through torch.distributed they are launched one by one.
     graph = None
     if world == 1:
         graph = graph_of([(lambda i=i: step(i)) for i in range(NBUF)], stream)
+    elif direct is not None:
+        try:
+            graph = graph_of([(lambda i=i: step(i)) for i in range(NBUF)], stream)
+        except Exception as e:  # noqa: BLE001 - same collective sequence either way, so ranks may differ here
+            collective = f"RCCL called directly, launched eagerly (capture failed: {type(e).__name__})"
+            print(f"[bench] rank {rank}: capturing the step failed: {e}", file=sys.stderr, flush=True)
 
     def run_steps(n):
         done = 0
@@ -332,6 +373,7 @@ def main():
             e1.synchronize()
         tp["all_reduce_us"] = e0.elapsed_time(e1) * 1e3 / 64
         tp["all_reduce_bytes"] = 2 * M * N
+        tp["collective"] = collective
 
     p2p = decode_tp = None
     if world > 1 and not args.no_p2p:
@@ -427,6 +469,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        if direct is not None:
+            direct.destroy_process_group()
         dist.destroy_process_group()
 
 

@@ -18,6 +18,7 @@ benchmarks/benchmark_latency.py:59-65).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -252,8 +253,24 @@ def main():
         if a.p2p_all_reduce:
             from vllm_quick_amd.parallel_utils import custom_all_reduce as car
             car.init_custom_ar()
+        elif a.backend == "nccl":
+            # a decode step is captured in a HIP graph, where torch.distributed's RCCL path cannot
+            # be used: a communicator of this harness's own (vllm/worker/worker.py:257-262 sets up
+            # the reference's CuPy one the same way)
+            import socket
+            from vllm_quick_amd.parallel_utils import rccl_utils
+            port = [0]
+            if dist.get_rank() == 0:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    port[0] = sock.getsockname()[1]
+            dist.broadcast_object_list(port, src=0)
+            rccl_utils.init_process_group(world, dist.get_rank(), "127.0.0.1", port[0])
     t0 = time.time()
-    out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx, fuse_act=not a.no_fuse_act)
+    from vllm_quick_amd.parallel_utils import rccl_utils as direct
+    with (ps.with_rccl_for_all_reduce() if direct.is_initialized() else contextlib.nullcontext()):
+        out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx,
+                  fuse_act=not a.no_fuse_act)
     out["wall_s"] = time.time() - t0
     out["all_reduce"] = "peer-to-peer kernel" if world > 1 and a.p2p_all_reduce else ("rccl" if world > 1 else None)
     if world > 1 and a.p2p_all_reduce:
@@ -263,6 +280,7 @@ def main():
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(out))
     if world > 1:
+        direct.destroy_process_group()
         dist.destroy_process_group()
 
 
