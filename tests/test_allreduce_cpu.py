@@ -163,3 +163,15 @@ def test_weak_contiguity_examples_of_the_reference():
     A = torch.zeros(3, 3, 3)
     assert ok(A) and ok(A[1:]) and ok(A.permute(2, 0, 1)) and ok(A[1:].permute(2, 0, 1))
     assert not ok(A[None].expand(2, -1, -1, -1)) and not ok(A[:, 1:, 1:])
+
+
+def test_direct_rccl_context_is_a_no_op_for_one_rank():
+    """parallel_state.py:226-230: nothing is switched (or created) when there is nothing to reduce."""
+    from vllm_quick_amd.parallel_utils import parallel_state as ps
+    from vllm_quick_amd.parallel_utils import rccl_utils
+    with ps.with_rccl_for_all_reduce():
+        assert not ps.is_rccl_enabled_for_all_reduce()
+    assert not rccl_utils.is_initialized() and rccl_utils.get_world_size() == 0
+    rccl_utils.destroy_process_group()  # harmless without a communicator
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclGetErrorString"):
+        assert hasattr(rccl_utils._library(), name)

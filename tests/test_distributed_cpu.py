@@ -55,6 +55,21 @@ def _worker(rank, world, port, q):
         g0 = comm.tensor_model_parallel_all_gather(torch.full((2, 3), float(rank)), dim=0)
         assert g0.shape == (2 * world, 3) and torch.equal(g0[2 * rank], torch.full((3, ), float(rank)))
 
+        # inside with_rccl_for_all_reduce() (graph capture) the all-reduce goes to the direct binding
+        # (parallel_state.py:217-245, communication_op.py:35-37); a stand-in records the routing here
+        seen = []
+        real = comm.rccl_utils.all_reduce
+        comm.rccl_utils.all_reduce = lambda t: (seen.append(tuple(t.shape)), dist.all_reduce(t))[1]
+        assert not ps.is_rccl_enabled_for_all_reduce()
+        with ps.with_cupy_nccl_for_all_reduce():
+            assert ps.is_cupy_nccl_enabled_for_all_reduce()
+            r = comm.tensor_model_parallel_all_reduce(torch.full((2, 2), float(rank + 1)))
+        comm.rccl_utils.all_reduce = real
+        assert seen == [(2, 2)] and torch.equal(r, torch.full((2, 2), 3.0))
+        assert not ps.is_rccl_enabled_for_all_reduce()
+        comm.tensor_model_parallel_all_reduce(torch.ones(2))
+        assert seen == [(2, 2)]
+
         M, K, N = 5, 128, 192
         x, qw, s, qz = orc.make_inputs(M, K, N, 32, seed=41)
         want = orc.gemm_faithful(x, qw, s, qz).astype(np.float32)
