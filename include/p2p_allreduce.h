@@ -53,7 +53,7 @@ enum {
   P2P_AR_E_ALIGN = -4,     /* input or output not 16-byte aligned                                             */
   P2P_AR_E_DTYPE = -5,     /* element type not f32 / f16 / bf16 (custom_all_reduce.cu:95-97)                  */
   P2P_AR_E_HIP = -6,       /* a HIP runtime call failed; see p2p_ar_last_hip_error()                          */
-  P2P_AR_E_STATE = -7      /* context not connected yet, or connected twice                                   */
+  P2P_AR_E_STATE = -7      /* context not connected yet, connected twice, or its GPU is not the current device */
 };
 
 enum { P2P_AR_F32 = 0, P2P_AR_F16 = 1, P2P_AR_BF16 = 2 };

@@ -253,3 +253,41 @@ def test_two_contexts_in_one_process():
         torch.cuda.synchronize()
         for c in ctxs:
             L.p2p_ar_destroy(c)
+
+
+def test_a_missing_peer_ends_in_a_status_flag_not_a_hang():
+    """Rank 0 calls, rank 1 never does: the kernel must give up after the context's timeout."""
+    import time
+
+    from vllm_quick_amd import _p2p_lib as P
+    L = P.lib
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctxs = [ctypes.c_void_p() for _ in range(2)]
+    for r in range(2):
+        P.check(L.p2p_ar_create(r, 2, 1 << 20, ctypes.byref(ctxs[r])), "create")
+    try:
+        boxes = (ctypes.c_void_p * 2)(*[L.p2p_ar_mailbox_ptr(c) for c in ctxs])
+        for c in ctxs:
+            P.check(L.p2p_ar_connect_ptrs(c, boxes), "connect")
+        P.check(L.p2p_ar_set_timeout_ms(ctxs[0], 300), "timeout")
+        assert L.p2p_ar_set_timeout_ms(ctxs[0], 0) == -3
+        x = torch.ones(4096, dtype=torch.float16, device=dev)
+        y = torch.empty_like(x)
+        flag = ctypes.c_int(0)
+        P.check(L.p2p_ar_status(ctxs[0], ctypes.byref(flag), 0), "status")
+        assert flag.value == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        P.check(L.p2p_ar_all_reduce(ctxs[0], x.data_ptr(), y.data_ptr(), x.numel(), P.F16, None), "all_reduce")
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+        assert 0.25 < waited < 5.0, f"gave up after {waited:.3f} s, timeout was 0.3 s"
+        P.check(L.p2p_ar_status(ctxs[0], ctypes.byref(flag), 1), "status")
+        assert flag.value == 1
+        P.check(L.p2p_ar_status(ctxs[0], ctypes.byref(flag), 0), "status")
+        assert flag.value == 0, "clear must reset the sticky flag"
+    finally:
+        torch.cuda.synchronize()
+        for c in ctxs:
+            L.p2p_ar_destroy(c)

@@ -327,7 +327,7 @@ const char* p2p_ar_strerror(int code) {
     case P2P_AR_E_ALIGN: return "input and output must be 16-byte aligned";
     case P2P_AR_E_DTYPE: return "custom allreduce only supports float32, float16 and bfloat16";
     case P2P_AR_E_HIP: return "a HIP runtime call failed";
-    case P2P_AR_E_STATE: return "context is not connected to its peers (or already is)";
+    case P2P_AR_E_STATE: return "context is not connected to its peers (or already is), or its GPU is not the current device";
   }
   return "unknown error code";
 }
@@ -429,6 +429,9 @@ int p2p_ar_all_reduce(void* ctx, const void* in, void* out, int64_t numel, int d
   const int64_t bytes = numel * esize;
   if (bytes % 16 != 0) return P2P_AR_E_SIZE;
   if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) return P2P_AR_E_ALIGN;
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev != c->device) return P2P_AR_E_STATE;  // the mailbox and the call counter live on the context's GPU
 
   ArArgs a;
   a.in = static_cast<const uint4*>(in);
