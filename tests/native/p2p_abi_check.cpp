@@ -137,7 +137,9 @@ int main(int argc, char** argv) {
     if (pid == 0) {
       close(a[0]), close(b[1]);
       for (int q = 0; q < r; ++q) close(up[q]), close(down[q]);
-      _exit(run_rank(r, world, a[1], b[0]));
+      const int rc = run_rank(r, world, a[1], b[0]);
+      std::fflush(stdout);
+      _exit(rc);
     }
     close(a[1]), close(b[0]);
     up[r] = a[0], down[r] = b[1], pids[r] = pid;
