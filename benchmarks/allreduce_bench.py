@@ -72,6 +72,68 @@ def time_eager(fn, stream, n=64):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def time_steps(fa, rank, world, dev, stream, rccl, nsets=8):
+    import socket
+
+    from bench import GROUP, K_IN, M_HEADLINE, N_OUT, make_weights, make_x
+    from vllm_quick_amd._C import ops
+    from vllm_quick_amd.parallel_utils import rccl_utils
+    K, N, G, M, p = K_IN, N_OUT, GROUP, M_HEADLINE, world
+    if N % (8 * p) or (K // p) % G:
+        raise RuntimeError(f"{K}x{N} g{G} cannot be sharded {p} ways")
+    col, row = [], []
+    for i in range(nsets):
+        qw, s, qz = make_weights(K, N, G, seed=i, device=dev)
+        nc, n, kk, gg = N // 8 // p, N // p, K // p, K // G // p
+        col.append(ops.awq_repack(qw[:, rank * nc:(rank + 1) * nc].contiguous(), s[:, rank * n:(rank + 1) * n].contiguous(),
+                                  qz[:, rank * nc:(rank + 1) * nc].contiguous()))
+        row.append(ops.awq_repack(qw[rank * kk:(rank + 1) * kk].contiguous(), s[rank * gg:(rank + 1) * gg].contiguous(),
+                                  qz[rank * gg:(rank + 1) * gg].contiguous()))
+    x_full = make_x(M, K, seed=1234, device=dev)
+    x_row = x_full[:, rank * (K // p):(rank + 1) * (K // p)].contiguous()
+    res = {"weight_sets": nsets, "M": M}
+    if rccl:
+        port = [0]
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+        dist.broadcast_object_list(port, src=0)
+        rccl_utils.init_process_group(world, rank, "127.0.0.1", port[0])
+
+    def run(reduce_fn):
+        def steps():
+            for i in range(nsets):
+                ops.awq_gemm_packed(x_full, col[i])
+                reduce_fn(ops.awq_gemm_packed(x_row, row[i]))
+        with torch.cuda.stream(stream):
+            steps()
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                steps()
+            g.replay()
+            stream.synchronize()
+            ts = []
+            for _ in range(10):
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                g.replay()
+                e1.record(stream)
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / nsets)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    res["gemms_only_us"] = run(lambda y: y)
+    res["with_p2p_us"] = run(lambda y: fa.all_reduce_reg(y, y))
+    if rccl:
+        res["with_rccl_us"] = run(lambda y: rccl_utils.all_reduce(y))
+        rccl_utils.destroy_process_group()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, also the comparison) or gloo (control plane only)")
@@ -153,6 +215,12 @@ def main():
                     out["sizes"][name]["rccl_graph_us"] = time_graph(lambda: dist.all_reduce(z), stream)
             except Exception as e:  # noqa: BLE001
                 out["rccl_graph_error"] = f"{type(e).__name__}: {e}"
+        # the benchmark layer's tensor-parallel step (column-parallel GEMM, row-parallel GEMM, all-reduce of
+        # its [128, 11008] output), replayed from a HIP graph, with either collective inside
+        try:
+            out["step"] = time_steps(fa, rank, world, dev, stream, rccl)
+        except Exception as e:  # noqa: BLE001
+            out["step_error"] = f"{type(e).__name__}: {e}"
         car.destroy_custom_ar()
     except Exception as e:  # noqa: BLE001 - reported, not raised: this is a measurement aid
         out["ok"] = False
