@@ -39,7 +39,7 @@ def time_graph(fn, stream, reps=10):
         fn()
         stream.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             for _ in range(PER_GRAPH):
                 fn()
         g.replay()

@@ -182,7 +182,9 @@ def time_graph(fn, stream, reps=20):
             fn()  # warm-up: repacks every layer's weights
         stream.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        # thread-local capture mode: a process group's helper threads may call the runtime meanwhile
+        mode = "thread_local" if dist.is_initialized() else "global"
+        with torch.cuda.graph(g, stream=stream, capture_error_mode=mode):
             fn()
         g.replay()
         stream.synchronize()
