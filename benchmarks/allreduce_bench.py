@@ -72,12 +72,10 @@ def time_eager(fn, stream, n=64):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def time_steps(fa, rank, world, dev, stream, rccl, nsets=8):
-    import socket
-
+def time_steps(fa, rank, world, dev, stream, direct, nsets=8):
+    """`direct`: the initialised rccl_utils module, or None (no RCCL comparison)."""
     from bench import GROUP, K_IN, M_HEADLINE, N_OUT, make_weights, make_x
     from vllm_quick_amd._C import ops
-    from vllm_quick_amd.parallel_utils import rccl_utils
     K, N, G, M, p = K_IN, N_OUT, GROUP, M_HEADLINE, world
     if N % (8 * p) or (K // p) % G:
         raise RuntimeError(f"{K}x{N} g{G} cannot be sharded {p} ways")
@@ -92,14 +90,6 @@ def time_steps(fa, rank, world, dev, stream, rccl, nsets=8):
     x_full = make_x(M, K, seed=1234, device=dev)
     x_row = x_full[:, rank * (K // p):(rank + 1) * (K // p)].contiguous()
     res = {"weight_sets": nsets, "M": M}
-    if rccl:
-        port = [0]
-        if rank == 0:
-            with socket.socket() as sock:
-                sock.bind(("127.0.0.1", 0))
-                port[0] = sock.getsockname()[1]
-        dist.broadcast_object_list(port, src=0)
-        rccl_utils.init_process_group(world, rank, "127.0.0.1", port[0])
 
     def run(reduce_fn):
         def steps():
@@ -128,9 +118,8 @@ def time_steps(fa, rank, world, dev, stream, rccl, nsets=8):
 
     res["gemms_only_us"] = run(lambda y: y)
     res["with_p2p_us"] = run(lambda y: fa.all_reduce_reg(y, y))
-    if rccl:
-        res["with_rccl_us"] = run(lambda y: rccl_utils.all_reduce(y))
-        rccl_utils.destroy_process_group()
+    if direct is not None:
+        res["with_rccl_us"] = run(lambda y: direct.all_reduce(y))
     return res
 
 
@@ -207,20 +196,39 @@ def main():
         oks = [None] * world
         dist.all_gather_object(oks, out["ok"])
         out["ok_all_ranks"] = all(oks)
+        if rank == 0:
+            print(json.dumps(out), flush=True)  # what is known so far, should anything below end the process
+        direct = None
         if rccl:
-            # the collective library replayed from a graph too; last, so that a refused capture costs nothing else
+            # the collective library replayed from a graph too: called directly (torch.distributed's RCCL path
+            # aborts the process when captured)
             try:
+                import socket
+
+                from vllm_quick_amd.parallel_utils import rccl_utils
+                port = [0]
+                if rank == 0:
+                    with socket.socket() as sock:
+                        sock.bind(("127.0.0.1", 0))
+                        port[0] = sock.getsockname()[1]
+                dist.broadcast_object_list(port, src=0)
+                rccl_utils.init_process_group(world, rank, "127.0.0.1", port[0])
+                direct = rccl_utils
                 for name, n in sizes:
                     z = torch.ones(n, dtype=torch.float16, device=dev)
-                    out["sizes"][name]["rccl_graph_us"] = time_graph(lambda: dist.all_reduce(z), stream)
+                    out["sizes"][name]["rccl_graph_us"] = time_graph(lambda: direct.all_reduce(z), stream)
             except Exception as e:  # noqa: BLE001
                 out["rccl_graph_error"] = f"{type(e).__name__}: {e}"
+            if rank == 0:
+                print(json.dumps(out), flush=True)
         # the benchmark layer's tensor-parallel step (column-parallel GEMM, row-parallel GEMM, all-reduce of
         # its [128, 11008] output), replayed from a HIP graph, with either collective inside
         try:
-            out["step"] = time_steps(fa, rank, world, dev, stream, rccl)
+            out["step"] = time_steps(fa, rank, world, dev, stream, direct)
         except Exception as e:  # noqa: BLE001
             out["step_error"] = f"{type(e).__name__}: {e}"
+        if direct is not None:
+            direct.destroy_process_group()
         car.destroy_custom_ar()
     except Exception as e:  # noqa: BLE001 - reported, not raised: this is a measurement aid
         out["ok"] = False
