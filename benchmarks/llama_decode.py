@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 from vllm_quick_amd._C import ops  # noqa: E402,F401
 from vllm_quick_amd.layers.activation import gate_up_silu_and_mul  # noqa: E402
 from vllm_quick_amd.layers.linear import (MergedColumnParallelLinear, QKVParallelLinear,  # noqa: E402
-                                          RowParallelLinear)
+                                          RowParallelLinear, row_parallel_add_)
 from vllm_quick_amd.layers.quantization import AWQConfig  # noqa: E402
 from vllm_quick_amd.parallel_utils import parallel_state as ps  # noqa: E402
 
@@ -92,6 +92,7 @@ class DecoderLayer(torch.nn.Module):
         self.down_proj = RowParallelLinear(cfg["inter"], h, bias=False, params_dtype=torch.float16,
                                            linear_method=method)
         self.fuse_act = True
+        self.fuse_add = True
         self.ln1 = torch.ones(h, dtype=torch.float16, device=device)
         self.ln2 = torch.ones(h, dtype=torch.float16, device=device)
         self.k_cache = torch.zeros(max_bs, self.n_kv, max_len, self.head_dim, dtype=torch.float16, device=device)
@@ -114,8 +115,11 @@ class DecoderLayer(torch.nn.Module):
         self.v_cache[:bs, :, pos:pos + 1] = v
         kk, vv = self.k_cache[:bs, :, :ctx_len], self.v_cache[:bs, :, :ctx_len]
         att = F.scaled_dot_product_attention(q, kk, vv, enable_gqa=self.n_kv != self.n_heads)
-        o, _ = self.o_proj(att.reshape(bs, -1))
-        x = x + o
+        if self.fuse_add:
+            x = row_parallel_add_(self.o_proj, att.reshape(bs, -1), x)  # x is this step's own buffer
+        else:
+            o, _ = self.o_proj(att.reshape(bs, -1))
+            x = x + o
         hdn = self.rms(x, self.ln2)
         if self.fuse_act:
             act = gate_up_silu_and_mul(self.gate_up_proj, hdn)  # activation in the GEMM epilogue
@@ -123,6 +127,8 @@ class DecoderLayer(torch.nn.Module):
             gu, _ = self.gate_up_proj(hdn)
             g, u = gu.chunk(2, -1)
             act = F.silu(g) * u
+        if self.fuse_add:
+            return row_parallel_add_(self.down_proj, act, x)  # residual add in the GEMM epilogue
         d, _ = self.down_proj(act)
         return x + d
 
@@ -201,7 +207,7 @@ def time_graph(fn, stream, reps=20):
 
 
 def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None,
-        fuse_act=True):
+        fuse_act=True, fuse_add=True):
     cfg = SHAPES[model_name]
     device = device or torch.device("cuda", torch.cuda.current_device())
     n_layers = n_layers or cfg["layers"]
@@ -209,6 +215,7 @@ def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ct
         model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device)
         for layer in model.layers:
             layer.fuse_act = fuse_act
+            layer.fuse_add = fuse_add
         stream = torch.cuda.Stream(device=device)
         res = {}
         for bs in batch_sizes:
@@ -226,6 +233,7 @@ def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ct
     return {"model": f"llama-2-{model_name}-awq-shaped (synthetic weights, g128)", "layers_run": n_layers,
             "layers_model": cfg["layers"], "context": ctx_len, "tp": ps.get_tensor_model_parallel_world_size(),
             "gate_up_activation": "fused into the GEMM epilogue" if fuse_act else "separate elementwise ops",
+            "residual_add": "fused into the o_proj / down_proj GEMM epilogue (one rank)" if fuse_add else "separate op",
             "by_batch": res}
 
 
@@ -236,6 +244,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=128)
     ap.add_argument("--no-fuse-act", action="store_true", help="run gate_up GEMM and silu-and-mul as separate ops")
+    ap.add_argument("--no-fuse-add", action="store_true", help="add the o_proj / down_proj outputs to the residual "
+                    "stream as separate ops")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL), or gloo for a "
                     "rehearsal (then every all-reduce must take the peer-to-peer path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -272,7 +282,7 @@ def main():
     from vllm_quick_amd.parallel_utils import rccl_utils as direct
     with (ps.with_rccl_for_all_reduce() if direct.is_initialized() else contextlib.nullcontext()):
         out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx,
-                  fuse_act=not a.no_fuse_act)
+                  fuse_act=not a.no_fuse_act, fuse_add=not a.no_fuse_add)
     out["wall_s"] = time.time() - t0
     out["all_reduce"] = "peer-to-peer kernel" if world > 1 and a.p2p_all_reduce else ("rccl" if world > 1 else None)
     if world > 1 and a.p2p_all_reduce:

@@ -173,9 +173,14 @@ int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, c
  *                       (csrc/activation_kernels.cu:9-34): silu in fp32 on the fp16 GEMM result,
  *                       rounded to fp16, then an fp16 multiply, as there; the [M, N] intermediate
  *                       never reaches memory.  Built launch shapes only (W4A16_E_SHAPE otherwise).
+ *   W4A16_EPI_ADD_TO_OUT  out [M, N] = out + (x @ W (+ bias)): the fp16 GEMM result (rounded once, bias
+ *                       added in fp16) is added in fp16 to what `out` holds, i.e. the
+ *                       `residual + linear(x)` of a decoder layer (vllm/model_executor/models/llama.py:
+ *                       the o_proj and down_proj outputs are added to the residual stream) with `out` the
+ *                       residual buffer, updated in place; bit-identical to the two separate steps.
  * out_batch_stride >= M * (columns of out).
  */
-enum { W4A16_EPI_NONE = 0, W4A16_EPI_SILU_MUL = 1 };
+enum { W4A16_EPI_NONE = 0, W4A16_EPI_SILU_MUL = 1, W4A16_EPI_ADD_TO_OUT = 2 };
 int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void* packed_w,
                              const void* packed_sz, const void* bias, void* out,
                              long long out_batch_stride, int M, int K, int N, int G, int batch,

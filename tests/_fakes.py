@@ -58,3 +58,9 @@ class FakeOps:
         half = y.shape[-1] // 2
         g = y[..., :half].float()
         return (g / (1.0 + torch.exp(-g))).half() * y[..., half:]
+
+    def awq_gemm_packed_add_(self, out, x, packed, bias=None, cfg=None):
+        self.trace.append(["awq_gemm_add_", list(x.shape)])
+        y = self.awq_gemm_packed(x, packed, bias)
+        self.trace.pop()
+        return out.add_(y)

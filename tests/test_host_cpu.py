@@ -285,3 +285,35 @@ def test_gate_up_silu_and_mul_uses_the_fused_call(monkeypatch):
         want = SiluAndMul()(torch.cat([g, u], -1))
         assert y.shape == (tokens, 64)
         assert np.allclose(y.float().numpy(), want.float().numpy(), rtol=2e-2, atol=2e-3)
+
+
+def test_row_parallel_add_uses_the_fused_call(monkeypatch):
+    """`residual + o_proj(x)` / `residual + down_proj(x)` of a decoder layer (llama.py:197-223): one
+    fused operator call below the large-batch switch point, GEMM then add above it; the same bits as
+    the two separate steps either way, and the residual is updated in place."""
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    method = awq_mod.AWQLinearMethod(AWQConfig(4, 32, True), fp16_matmul_threshold=4)
+    layer = L.RowParallelLinear(64, 96, bias=True, params_dtype=torch.float16, linear_method=method)
+    ck = ckpt(64, 96, 31)
+    for n in ck:
+        p = getattr(layer, n)
+        p.weight_loader(p, torch.from_numpy(ck[n]))
+    layer.bias.data.copy_(torch.linspace(-1, 1, 96).half())
+    for tokens, want_ops in ((3, ["awq_gemm_add_"]), (4, ["awq_dequantize"])):
+        x = torch.from_numpy(orc.make_inputs(tokens, 64, 96, 32, seed=33)[0])
+        res = (torch.arange(tokens * 96).reshape(tokens, 96) % 13 - 6).half() * 0.25
+        want = res + layer(x)[0]
+        del fake.trace[:]
+        got = L.row_parallel_add_(layer, x, res)
+        assert got is res
+        assert [t[0] for t in fake.trace if t[0] != "repack"] == want_ops
+        assert torch.equal(got, want)
+    # a layer that hands its bias back to the caller takes the two-step route
+    layer.skip_bias_add = True
+    x = torch.from_numpy(orc.make_inputs(2, 64, 96, 32, seed=34)[0])
+    res = torch.zeros(2, 96, dtype=torch.float16)
+    del fake.trace[:]
+    L.row_parallel_add_(layer, x, res)
+    assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm"]
+    assert torch.equal(res, layer(x)[0])

@@ -254,7 +254,7 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
     return out
 
 
-EPI_NONE, EPI_SILU_MUL = 0, 1
+EPI_NONE, EPI_SILU_MUL, EPI_ADD_TO_OUT = 0, 1, 2
 
 
 def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
@@ -298,6 +298,42 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
                                           packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * half, M,
                                           packed.K, packed.N, packed.G, E, EPI_SILU_MUL, mt, t, a, b, _stream())
         check(rc, "awq_gemm_silu_and_mul")
+    return out
+
+
+def awq_gemm_packed_add_(out: torch.Tensor,
+                         in_feats: torch.Tensor,
+                         packed: PackedAWQ,
+                         bias: Optional[torch.Tensor] = None,
+                         cfg: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+    """out += in_feats @ W (+ bias), in place, in one launch: `residual + linear(x)` of a decoder layer
+    with `out` the residual stream.  The GEMM result is rounded to fp16 (bias added in fp16) and then
+    added in fp16, exactly as the two separate operations would."""
+    _require(in_feats, torch.float16, "in_feats")
+    _require(out, torch.float16, "out")
+    if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
+        raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
+    M = in_feats.shape[0]
+    if tuple(out.shape) != (M, packed.N) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{M}, {packed.N}] tensor, got {tuple(out.shape)}")
+    if in_feats.device != packed.device or out.device != packed.device:
+        raise RuntimeError("in_feats, out and the packed weights must be on one device")
+    x = in_feats.contiguous()
+    bias_ptr = None
+    if bias is not None:
+        _require(bias, torch.float16, "bias")
+        if bias.numel() != packed.N:
+            raise ValueError(f"bias must have {packed.N} elements")
+        bias = bias.contiguous()
+        bias_ptr = bias.data_ptr()
+    if M == 0:
+        return out
+    with _on_device(x.device):
+        mt, t, a, b = (0, 0, 0, 0) if cfg is None else (tuple(cfg) + (0, ))[:4]
+        rc = lib.w4a16_gemm_packed_f16_ex(x.data_ptr(), 0, packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
+                                          bias_ptr, out.data_ptr(), M * packed.N, M, packed.K, packed.N, packed.G, 1,
+                                          EPI_ADD_TO_OUT, mt, t, a, b, _stream())
+        check(rc, "awq_gemm_add_")
     return out
 
 

@@ -167,6 +167,7 @@ struct GemmArgs {
   int M, K, N, G;
   int NT, KB, NG;
   int KBS;  // 128-k blocks per column tile in the packed layout (KB rounded up to a multiple of 4)
+  int add_out;  // epilogue: out = out + fp16 result (the residual stream updated in place)
   // Batched launches (gridDim.z problems of one shape): element strides from one problem to the
   // next; all zero for a single GEMM.  x_bs == 0 shares the activations between the problems.
   long long x_bs, out_bs, pw_bs, psz_bs, bias_bs;
@@ -178,7 +179,7 @@ struct GemmArgs {
 // before the first global load can be issued.
 __device__ __forceinline__ void fetch_args_now(const GemmArgs& g) {
   asm volatile("" ::"s"(g.x), "s"(g.pw), "s"(g.psz), "s"(g.bias), "s"(g.out), "s"(g.M), "s"(g.K), "s"(g.N),
-               "s"(g.G), "s"(g.NT), "s"(g.KB), "s"(g.NG), "s"(g.KBS));
+               "s"(g.G), "s"(g.NT), "s"(g.KB), "s"(g.NG), "s"(g.KBS), "s"(g.add_out));
   asm volatile("" ::"s"(g.x_bs), "s"(g.out_bs), "s"(g.pw_bs), "s"(g.psz_bs), "s"(g.bias_bs));
 }
 
@@ -391,7 +392,13 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       if (nt < NTH && m < a.M)
         *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
     } else {
-      if (nt < a.NT && n < a.N && m < a.M) *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = finish(v, n);
+      if (nt < a.NT && n < a.N && m < a.M) {
+        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+        f16x4 h = finish(v, n);
+        // fp16 + fp16, as `residual + linear(x)` on fp16 tensors; one lane owns each element
+        if (a.add_out) h = *dst + h;
+        *dst = h;
+      }
     }
   };
   constexpr int OUTS = H * MT;  // stores per workgroup: tiles, or gate/up tile pairs
@@ -715,7 +722,9 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
     } else {
       if (nt < a.NT && n < a.N && m < a.M) {
         if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n);
-        *reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n) = h;
+        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+        if (a.add_out) h = *dst + h;  // fp16 + fp16; one lane owns each element
+        *dst = h;
       }
     }
   };
@@ -987,6 +996,7 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   a->KB = ceil_div(K, 128);
   a->KBS = padded_kblocks(K);
   a->NG = K / G;
+  a->add_out = 0;
   a->x_bs = a->out_bs = a->pw_bs = a->psz_bs = a->bias_bs = 0;
   if (batch != 1) {
     if (batch < 1 || batch > 65535) return W4A16_E_SHAPE;
@@ -1375,7 +1385,8 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
                                long long out_batch_stride, int M, int K, int N, int G, int batch,
                                int epilogue, int mt, int t, int a_, int b_, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
-  if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL) return W4A16_E_SHAPE;
+  if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL && epilogue != W4A16_EPI_ADD_TO_OUT)
+    return W4A16_E_SHAPE;
   const bool act = epilogue == W4A16_EPI_SILU_MUL;
   if (act && N % 32) return W4A16_E_SHAPE;  // two halves of whole 16-column tiles
   const long long out_cols = act ? N / 2 : N;
@@ -1389,6 +1400,7 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
     a.out_bs = out_batch_stride;
   }
   if ((long long)batch * out_batch_stride >= (1LL << 40)) return W4A16_E_TOO_LARGE;
+  a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
   clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
   if (mt == 0) {

@@ -326,3 +326,17 @@ class RowParallelLinear(_LinearBase):
         if self.skip_bias_add:
             return out, self.bias
         return (out + self.bias if self.bias is not None else out), None
+
+
+def row_parallel_add_(layer: "RowParallelLinear", x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    """residual += layer(x)[0], in place; returns `residual`.
+
+    What a decoder layer does with its o_proj and down_proj outputs (llama.py:197-223).  On one rank,
+    with a linear method that offers it (AWQ), the addition runs in the GEMM's epilogue; with tensor
+    parallelism the partial products must be summed over the ranks first, so the two-step route is taken.
+    """
+    fused = getattr(layer.linear_method, "apply_weights_add_", None)
+    if fused is None or layer.tp_size > 1 or layer.skip_bias_add:
+        y, _ = layer(x)
+        return residual.add_(y)
+    return fused(layer.linear_weights, x, residual, layer.bias)

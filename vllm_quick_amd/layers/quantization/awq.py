@@ -169,3 +169,16 @@ class AWQLinearMethod(LinearMethodBase):
             return torch.nn.functional.silu(y[..., :half]) * y[..., half:]
         out = ops.awq_gemm_packed_silu_and_mul(x.reshape(-1, x.shape[-1]), packed, bias=bias)
         return out.reshape(x.shape[:-1] + (n_out // 2, ))
+
+    def apply_weights_add_(self, weights: Dict[str, Any], x: torch.Tensor, residual: torch.Tensor,
+                           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """residual += apply_weights(weights, x, bias), in place; returns `residual`.  The `residual +
+        o_proj(...)` / `residual + down_proj(...)` of a decoder layer (llama.py:197-223) with the add in the
+        GEMM epilogue where the fused kernel serves the call; same bits as the two separate steps."""
+        num_tokens = x.shape[:-1].numel()
+        large = self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold
+        packed = None if large else self._packed(weights)
+        if packed is None or not residual.is_contiguous() or residual.dtype != torch.float16:
+            return residual.add_(self.apply_weights(weights, x, bias))
+        ops.awq_gemm_packed_add_(residual.view(-1, residual.shape[-1]), x.reshape(-1, x.shape[-1]), packed, bias=bias)
+        return residual
