@@ -110,6 +110,23 @@ static int check_case(int M, int K, int N, int G, bool with_bias) {
             "w4a16_gemm_packed_f16");
   compare(with_bias ? "gemm (packed) + bias  " : "gemm (packed)         ", with_bias);
 
+  {
+    // add-to-out epilogue: residual + (the result just checked), bit for bit the fp16 sum
+    std::vector<uint16_t> plain = got, res((size_t)M * N), sum((size_t)M * N);
+    for (auto& v : res) v = awq_c_f2h(normal());
+    HIP_OK(hipMemcpyAsync(d_out, res.data(), res.size() * 2, hipMemcpyHostToDevice, stream));
+    expect_ok(w4a16_gemm_packed_f16_ex(d_x, 0, d_pw, d_ps, with_bias ? d_bias : nullptr, d_out, (long long)M * N, M, K,
+                                       N, G, 1, W4A16_EPI_ADD_TO_OUT, 0, 0, 0, 0, stream),
+              "w4a16_gemm_packed_f16_ex(ADD_TO_OUT)");
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(sum.data(), d_out, sum.size() * 2, hipMemcpyDeviceToHost));
+    size_t diff = 0;
+    for (size_t i = 0; i < sum.size(); ++i) diff += sum[i] != awq_c_f2h(awq_c_h2f(res[i]) + awq_c_h2f(plain[i]));
+    std::printf("%s gemm (packed) += out   M=%d K=%d N=%d G=%d: %zu elements differ from the fp16 sum\n",
+                diff ? "FAIL" : "ok  ", M, K, N, G, diff);
+    fails += diff != 0;
+  }
+
   for (int packed = 0; packed < 2; ++packed) {
     expect_ok(packed ? w4a16_dequantize_packed_f16(d_pw, d_ps, d_deq, K, N, G, stream)
                      : w4a16_dequantize_f16(d_qw, d_sc, d_qz, d_deq, K, N, G, stream),
