@@ -40,10 +40,17 @@ def run(tokens=(1, 2, 4, 8, 16), experts=8, hidden=4096, inter=14336, top_k=2, d
             x = (torch.randn(1, t, hidden, generator=gen, device=device) * 0.25).half()
             moe.batched = True
             ms_b = time_graph(lambda: moe(x), stream)
+            keep, moe.sparse_max_tokens = moe.sparse_max_tokens, 0
+            ms_all = time_graph(lambda: moe(x), stream)  # every expert runs, as in the reference
+            moe.sparse_max_tokens = keep
             moe.batched = False
             ms_l = time_graph(lambda: moe(x), stream)
-            res[str(t)] = {"batched_ms": ms_b, "loop_ms": ms_l, "speedup": ms_l / ms_b,
-                           "batched_weight_GBps": wbytes / (ms_b * 1e-3) * 1e-9}
+            active = int((moe.routing(x.view(-1, hidden)) != 0).any(0).sum())
+            res[str(t)] = {"batched_ms": ms_b, "batched_all_experts_ms": ms_all, "loop_ms": ms_l,
+                           "speedup": ms_l / ms_b, "experts_selected": active,
+                           "experts_run": active if t <= keep else experts,
+                           "batched_weight_GBps": wbytes * (active if t <= keep else experts) / experts /
+                           (ms_b * 1e-3) * 1e-9}
     return {"block": f"mixtral-8x7b-shaped experts (E={experts}, {hidden}->{inter}->{hidden}, g128, synthetic)",
             "weight_bytes": wbytes, "by_tokens": res}
 

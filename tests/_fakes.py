@@ -37,21 +37,23 @@ class FakeOps:
         self.trace.append(["repack_batch", len(kernels)])
         return list(zip(kernels, scaling_factors, zeros))
 
-    def awq_gemm_packed_batched(self, x, packed, bias=None):
-        self.trace.append(["awq_gemm_batched", list(x.shape), len(packed)])
+    def awq_gemm_packed_batched(self, x, packed, bias=None, mask=None):
+        self.trace.append(["awq_gemm_batched", list(x.shape), len(packed)] +
+                          ([] if mask is None else [mask.tolist()]))
         outs = []
         for e, (qw, s, qz) in enumerate(packed):
             xe = x if x.dim() == 2 else x[e]
             y = torch.from_numpy(
                 orc.gemm_faithful(xe.contiguous().numpy(), qw.detach().numpy(), s.detach().numpy(),
                                   qz.detach().numpy()))
-            outs.append(y if bias is None else y + bias[e])
+            y = y if bias is None else y + bias[e]
+            outs.append(y if mask is None or int(mask[e]) else torch.zeros_like(y))  # skipped problems read as zero
         return torch.stack(outs)
 
-    def awq_gemm_packed_silu_and_mul(self, x, packed, bias=None, cfg=None):
-        self.trace.append(["awq_gemm_silu_and_mul", list(x.shape)])
+    def awq_gemm_packed_silu_and_mul(self, x, packed, bias=None, cfg=None, mask=None):
+        self.trace.append(["awq_gemm_silu_and_mul", list(x.shape)] + ([] if mask is None else [mask.tolist()]))
         if isinstance(packed, list):  # a batch: list of (qweight, scales, qzeros)
-            y = self.awq_gemm_packed_batched(x, packed, bias)
+            y = self.awq_gemm_packed_batched(x, packed, bias, mask=mask)
         else:
             y = self.awq_gemm_packed(x, packed, bias)
         self.trace.pop()

@@ -129,3 +129,86 @@ def test_mixtral_block_on_gpu(cuda):
         assert (np.abs(g - want) <= RTOL * np.abs(want) + ATOL * scale).all()
     # the two routes run the same kernels on the same numbers up to the final fp32-vs-fp16 expert sum
     assert (y.float() - y_loop.float()).abs().max().item() <= 2.0**-9 * scale
+
+
+@pytest.mark.parametrize("epilogue", [0, 1])
+@pytest.mark.parametrize("M", [1, 4, 40])
+def test_masked_batch_through_c_abi(L, cuda, M, epilogue):
+    """w4a16_gemm_packed_f16_masked: switched-on problems bit for bit what the unmasked launch writes,
+    switched-off problems' output untouched; the mask is device data."""
+    E, K, N, G = 5, 256, 224, 128
+    xs, ws = make_problems(E, M, K, N, G, 70, True)
+    lib = L.lib
+    wb, sb = lib.w4a16_packed_weight_bytes(K, N), lib.w4a16_packed_sz_bytes(K, N, G)
+    pw = torch.empty((E, wb), dtype=torch.uint8, device=cuda)
+    ps = torch.empty((E, sb), dtype=torch.uint8, device=cuda)
+    stream = torch.cuda.current_stream().cuda_stream
+    for e, (qw, s, qz) in enumerate(ws):
+        tq, ts, tz = dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda)
+        L.check(lib.w4a16_repack(tq.data_ptr(), ts.data_ptr(), tz.data_ptr(), pw[e].data_ptr(), ps[e].data_ptr(),
+                                 K, N, G, stream), "repack")
+    tx = dev_t(xs, cuda)
+    cols = N // 2 if epilogue else N
+    full = torch.empty((E, M, cols), dtype=torch.float16, device=cuda)
+    L.check(lib.w4a16_gemm_packed_f16_ex(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, full.data_ptr(),
+                                         M * cols, M, K, N, G, E, epilogue, 0, 0, 0, 0, stream), "ex")
+    for on in ([1, 0, 0, 1, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [0, 7, 0, 0, -1]):
+        mask = torch.tensor(on, dtype=torch.int32, device=cuda)
+        out = torch.full((E, M, cols), 123.0, dtype=torch.float16, device=cuda)
+        L.check(lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
+                                                 M * cols, M, K, N, G, E, epilogue, mask.data_ptr(), stream), "masked")
+        torch.cuda.synchronize()
+        for e in range(E):
+            if on[e]:
+                assert torch.equal(out[e], full[e]), (on, e)
+            else:
+                assert bool((out[e] == 123.0).all()), (on, e)
+    # no mask = every problem; a misaligned mask pointer is refused
+    out = torch.empty((E, M, cols), dtype=torch.float16, device=cuda)
+    L.check(lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
+                                             M * cols, M, K, N, G, E, epilogue, None, stream), "masked, no mask")
+    torch.cuda.synchronize()
+    assert torch.equal(out, full)
+    assert lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
+                                            M * cols, M, K, N, G, E, epilogue, mask.data_ptr() + 2, stream) == -6
+
+
+def test_mixtral_block_skips_unselected_experts_on_gpu(cuda):
+    """One to three tokens: the block with the per-expert switch (computed on the device) returns the very
+    bits of the block that runs every expert; also from a captured graph with fresh tokens per replay."""
+    from test_experts_cpu import fill
+    from vllm_quick_amd.layers import experts as X
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    E, top_k, H, I = 8, 2, 128, 224
+    moe = X.MixtralMoE(E, top_k, H, I, linear_method=AWQConfig(4, 32, True).get_linear_method(),
+                       params_dtype=torch.float16)
+    fill(moe, seed=19)
+    moe = moe.to(cuda)
+    rng = np.random.default_rng(3)
+    with torch.inference_mode():
+        for tokens in (1, 2, 3):
+            x = dev_t((rng.standard_normal((1, tokens, H)) * 0.5).astype(np.float16), cuda)
+            moe.sparse_max_tokens = 4
+            sparse = moe(x)
+            w = moe.routing(x.view(-1, H))
+            assert int((w != 0).any(0).sum()) <= top_k * tokens < E
+            moe.sparse_max_tokens = 0
+            dense = moe(x)
+            assert torch.equal(sparse, dense)
+        moe.sparse_max_tokens = 4
+        xg = torch.zeros((1, 1, H), dtype=torch.float16, device=cuda)
+        stream = torch.cuda.Stream(device=cuda)
+        with torch.cuda.stream(stream):
+            moe(xg)
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                yg = moe(xg)
+            for _ in range(3):
+                fresh = dev_t((rng.standard_normal((1, 1, H)) * 0.5).astype(np.float16), cuda)
+                xg.copy_(fresh)
+                g.replay()
+                stream.synchronize()
+                moe.sparse_max_tokens = 0
+                assert torch.equal(yg, moe(fresh))
+                moe.sparse_max_tokens = 4

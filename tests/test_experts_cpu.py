@@ -70,6 +70,7 @@ def test_parameter_tree_matches_the_reference_names(monkeypatch):
 
 def test_batched_block_matches_reference_loop(monkeypatch):
     moe, fake = make(monkeypatch)
+    moe.sparse_max_tokens = 0  # every expert runs, as in the reference
     ck, gate = fill(moe, seed=3)
     x = (np.random.default_rng(5).standard_normal((2, 3, 64)) * 0.5).astype(np.float16)
     y = moe(torch.from_numpy(x))
@@ -89,10 +90,43 @@ def test_batched_block_matches_reference_loop(monkeypatch):
     assert [t[0] for t in fake.trace].count("repack_batch") == 4
 
 
+def test_few_tokens_skip_the_experts_nobody_selected(monkeypatch):
+    """With one or two tokens the launches carry a per-expert switch: exactly the selected experts are on,
+    and the block's output is what running every expert (and multiplying by zero) gives."""
+    moe, fake = make(monkeypatch)
+    ck, gate = fill(moe, seed=12)
+    for tokens in (1, 2):
+        x = (np.random.default_rng(20 + tokens).standard_normal((1, tokens, 64)) * 0.5).astype(np.float16)
+        del fake.trace[:]
+        y = moe(torch.from_numpy(x))
+        calls = [t for t in fake.trace if t[0].startswith("awq_gemm")]
+        assert [c[0] for c in calls] == ["awq_gemm_silu_and_mul", "awq_gemm_batched"]
+        mask = calls[0][-1]
+        assert mask == calls[1][-1] and len(mask) == 4
+        logits = torch.from_numpy(x.reshape(tokens, 64)).float() @ torch.from_numpy(gate).float().t()
+        chosen = set(torch.topk(logits, 2, dim=-1).indices.flatten().tolist())
+        assert {i for i, on in enumerate(mask) if on} == chosen and 2 <= len(chosen) < 4
+        moe.sparse_max_tokens = 0
+        dense = moe(torch.from_numpy(x))
+        moe.sparse_max_tokens = 4
+        assert torch.equal(y, dense)
+        want = reference_block(x.reshape(tokens, 64), gate, ck, moe.expert_indicies, 2)
+        assert np.allclose(y.reshape(tokens, 64).numpy().astype(np.float32), want.astype(np.float32), rtol=1e-2,
+                           atol=2e-3)
+    # the separate-activation route switches its 2 E gate/up problems the same way
+    moe.fuse_act = False
+    del fake.trace[:]
+    y2 = moe(torch.from_numpy(x))
+    calls = [t for t in fake.trace if t[0].startswith("awq_gemm")]
+    assert calls[0][-1] == mask + mask and calls[1][-1] == mask
+    assert np.allclose(y2.float().numpy(), y.float().numpy(), rtol=1e-2, atol=2e-3)
+
+
 def test_separate_activation_route(monkeypatch):
     moe, fake = make(monkeypatch)
     assert moe.fuse_act  # K of w2 is a multiple of the group size, hence of 16: always tile-aligned
     moe.fuse_act = False
+    moe.sparse_max_tokens = 0
     ck, gate = fill(moe, seed=8)
     x = (np.random.default_rng(9).standard_normal((1, 4, 64)) * 0.5).astype(np.float16)
     y = moe(torch.from_numpy(x))

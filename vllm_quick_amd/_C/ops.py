@@ -206,13 +206,25 @@ def awq_repack_batch(kernels, scaling_factors, zeros) -> PackedAWQBatch:
     return PackedAWQBatch(pw, ps, K, N, G)
 
 
+def _problem_mask(mask: Optional[torch.Tensor], E: int, device: torch.device, cfg) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    if cfg is not None:
+        raise ValueError("a problem mask goes with the library's own launch shape (cfg=None)")
+    if mask.dtype != torch.int32 or tuple(mask.shape) != (E, ) or mask.device != device or not mask.is_contiguous():
+        raise ValueError(f"mask must be a contiguous int32 [{E}] tensor on {device}")
+    return mask
+
+
 def awq_gemm_packed_batched(in_feats: torch.Tensor,
                             packed: PackedAWQBatch,
                             bias: Optional[torch.Tensor] = None,
-                            cfg: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+                            cfg: Optional[Tuple[int, ...]] = None,
+                            mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One launch for E GEMMs of one shape: in_feats [M, K] (shared by all problems) or [E, M, K] fp16,
     optional bias [E, N] -> [E, M, N] fp16.  Stands in for the reference's loop over experts
-    (mixtral_quant.py:145-157)."""
+    (mixtral_quant.py:145-157).  `mask` (int32 [E] on the device, read by the kernel): problems whose entry
+    is 0 are skipped, their weights never read, and their rows of the result are zero."""
     _require(in_feats, torch.float16, "in_feats")
     E = packed.batch
     if in_feats.dim() == 2:
@@ -234,8 +246,9 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
             raise ValueError(f"bias must be [{E}, {packed.N}]")
         bias = bias.contiguous()
         bias_ptr = bias.data_ptr()
+    mask = _problem_mask(mask, E, x.device, cfg)
     with _on_device(x.device):
-        out = torch.empty((E, M, packed.N), dtype=torch.float16, device=x.device)
+        out = (torch.empty if mask is None else torch.zeros)((E, M, packed.N), dtype=torch.float16, device=x.device)
         if M == 0:
             return out
         if (M * packed.K) % 8 and not shared:
@@ -245,7 +258,9 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
         common = (x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
                   packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * packed.N, M, packed.K, packed.N,
                   packed.G, E)
-        if cfg is None:
+        if mask is not None:
+            rc = lib.w4a16_gemm_packed_f16_masked(*common, EPI_NONE, mask.data_ptr(), _stream())
+        elif cfg is None:
             rc = lib.w4a16_gemm_packed_f16_batched(*common, _stream())
         else:  # (mt, t, waves) = streaming kernel, (mt, t, nw, kw) = LDS-staged kernel
             mt, t, a = cfg[:3]
@@ -260,11 +275,13 @@ EPI_NONE, EPI_SILU_MUL, EPI_ADD_TO_OUT = 0, 1, 2
 def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
                                  packed,
                                  bias: Optional[torch.Tensor] = None,
-                                 cfg: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+                                 cfg: Optional[Tuple[int, ...]] = None,
+                                 mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """silu(x @ W[:, :N/2]) * (x @ W[:, N/2:]) in one launch: the merged gate_up projection of a gated
     MLP with its activation fused into the GEMM epilogue (llama.py:74-80 of the reference runs the GEMM,
     then `silu_and_mul`).  `packed` is a PackedAWQ ([M, K] -> [M, N/2]) or a PackedAWQBatch ([M, K] shared
-    or [E, M, K] -> [E, M, N/2]); bias, if given, covers all N columns."""
+    or [E, M, K] -> [E, M, N/2]); bias, if given, covers all N columns.  `mask`: as for
+    `awq_gemm_packed_batched` (batches only)."""
     _require(in_feats, torch.float16, "in_feats")
     batched = isinstance(packed, PackedAWQBatch)
     E = packed.batch if batched else 1
@@ -287,16 +304,23 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
             raise ValueError(f"bias must have {E * packed.N} elements")
         bias = bias.contiguous()
         bias_ptr = bias.data_ptr()
+    if mask is not None and not batched:
+        raise ValueError("a problem mask needs a PackedAWQBatch")
+    mask = _problem_mask(mask, E, x.device, cfg)
     with _on_device(x.device):
-        out = torch.empty((E, M, half) if batched else (M, half), dtype=torch.float16, device=x.device)
+        out = (torch.empty if mask is None else torch.zeros)((E, M, half) if batched else (M, half),
+                                                             dtype=torch.float16, device=x.device)
         if M == 0:
             return out
         if batched and ((M * half) % 4 or (not shared and (M * packed.K) % 8)):
             raise ValueError("per-problem buffers must stay 8-byte (out) / 16-byte (in_feats) aligned")
         mt, t, a, b = (0, 0, 0, 0) if cfg is None else (tuple(cfg) + (0, ))[:4]
-        rc = lib.w4a16_gemm_packed_f16_ex(x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(),
-                                          packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * half, M,
-                                          packed.K, packed.N, packed.G, E, EPI_SILU_MUL, mt, t, a, b, _stream())
+        head = (x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
+                bias_ptr, out.data_ptr(), M * half, M, packed.K, packed.N, packed.G, E, EPI_SILU_MUL)
+        if mask is not None:
+            rc = lib.w4a16_gemm_packed_f16_masked(*head, mask.data_ptr(), _stream())
+        else:
+            rc = lib.w4a16_gemm_packed_f16_ex(*head, mt, t, a, b, _stream())
         check(rc, "awq_gemm_silu_and_mul")
     return out
 

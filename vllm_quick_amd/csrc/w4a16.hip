@@ -168,6 +168,7 @@ struct GemmArgs {
   int NT, KB, NG;
   int KBS;  // 128-k blocks per column tile in the packed layout (KB rounded up to a multiple of 4)
   int add_out;  // epilogue: out = out + fp16 result (the residual stream updated in place)
+  const int* mask;  // batched launches: problems whose entry is 0 are skipped (out untouched); may be null
   // Batched launches (gridDim.z problems of one shape): element strides from one problem to the
   // next; all zero for a single GEMM.  x_bs == 0 shares the activations between the problems.
   long long x_bs, out_bs, pw_bs, psz_bs, bias_bs;
@@ -179,7 +180,7 @@ struct GemmArgs {
 // before the first global load can be issued.
 __device__ __forceinline__ void fetch_args_now(const GemmArgs& g) {
   asm volatile("" ::"s"(g.x), "s"(g.pw), "s"(g.psz), "s"(g.bias), "s"(g.out), "s"(g.M), "s"(g.K), "s"(g.N),
-               "s"(g.G), "s"(g.NT), "s"(g.KB), "s"(g.NG), "s"(g.KBS), "s"(g.add_out));
+               "s"(g.G), "s"(g.NT), "s"(g.KB), "s"(g.NG), "s"(g.KBS), "s"(g.add_out), "s"(g.mask));
   asm volatile("" ::"s"(g.x_bs), "s"(g.out_bs), "s"(g.pw_bs), "s"(g.psz_bs), "s"(g.bias_bs));
 }
 
@@ -206,6 +207,8 @@ __device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
 template <int MT, int T, int W, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) {
   fetch_args_now(ga);
+  // a masked-out problem of a batched launch: the whole workgroup leaves before it touches memory
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
   const GemmArgs a = batch_slice(ga);
   constexpr int NSZ = 4 / SZS;  // scale/zero words per 128-k block and tile
   constexpr int TM = T * MT;
@@ -477,6 +480,8 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
                                                                    const GemmArgs ga) {
   fetch_args_now(ga);
   asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
+  // a masked-out problem of a batched launch: the whole workgroup leaves before it touches memory
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
   const GemmArgs a = batch_slice(ga);
   constexpr int NWAVES = NW * KW;
   constexpr int HW = ACT ? NW / 2 : NW;    // waves per half
@@ -997,6 +1002,7 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   a->KBS = padded_kblocks(K);
   a->NG = K / G;
   a->add_out = 0;
+  a->mask = nullptr;
   a->x_bs = a->out_bs = a->pw_bs = a->psz_bs = a->bias_bs = 0;
   if (batch != 1) {
     if (batch < 1 || batch > 65535) return W4A16_E_SHAPE;
@@ -1383,8 +1389,10 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
 static int gemm_packed_general(const void* x, long long x_batch_stride, const void* packed_w,
                                const void* packed_sz, const void* bias, void* out,
                                long long out_batch_stride, int M, int K, int N, int G, int batch,
-                               int epilogue, int mt, int t, int a_, int b_, void* stream) {
+                               int epilogue, int mt, int t, int a_, int b_, void* stream,
+                               const void* problem_mask = nullptr) {
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
+  if (problem_mask && (reinterpret_cast<uintptr_t>(problem_mask) & 3u)) return W4A16_E_ALIGN;
   if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL && epilogue != W4A16_EPI_ADD_TO_OUT)
     return W4A16_E_SHAPE;
   const bool act = epilogue == W4A16_EPI_SILU_MUL;
@@ -1401,6 +1409,7 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
   }
   if ((long long)batch * out_batch_stride >= (1LL << 40)) return W4A16_E_TOO_LARGE;
   a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
+  a.mask = static_cast<const int*>(problem_mask);
   clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
   if (mt == 0) {
@@ -1435,6 +1444,14 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
   if (mt < 0) return W4A16_E_SHAPE;
   return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
                              N, G, batch, epilogue, mt, t, a, b, stream);
+}
+
+int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const void* packed_w,
+                                 const void* packed_sz, const void* bias, void* out,
+                                 long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                 int epilogue, const void* problem_mask, void* stream) {
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
+                             N, G, batch, epilogue, 0, 0, 0, 0, stream, problem_mask);
 }
 
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,

@@ -15,6 +15,12 @@ takes three launches in total:
 
 followed by the routing-weighted sum over experts.  (`fuse_act = False` runs 2E separate gate/up
 problems and the activation as an elementwise step instead.)
+
+With few tokens most experts are selected by no token at all; the reference still runs them and
+multiplies their output by a routing weight of zero (:150-155).  Up to `sparse_max_tokens` (4) tokens
+the launches here carry a per-expert switch computed on the device from the routing weights (no
+host synchronisation, so the block stays capturable in a HIP graph): an unselected expert's weights
+are never read and its output counts as zero, which is what the multiplication by zero yields.
 """
 from __future__ import annotations
 
@@ -84,6 +90,9 @@ class MixtralMoE(torch.nn.Module):
                                      linear_method=None)
         self.batched = isinstance(linear_method, AWQLinearMethod)
         self.fuse_act = True  # the intermediate size is a multiple of the group size, hence of 16
+        # one token selects top_k experts; 4 tokens of a top-2-of-8 router still leave a third of them idle,
+        # beyond that the switch costs about what it saves
+        self.sparse_max_tokens = 4
         self._packed = None  # (stamp, fused?, w13 batch, w2 batch)
 
     # ------------------------------------------------------------------
@@ -140,12 +149,16 @@ class MixtralMoE(torch.nn.Module):
         else:
             b13, b2 = batches
             E = len(self.expert_indicies)
+            mask = None
+            if hidden_states.shape[0] <= self.sparse_max_tokens:
+                mask = (expert_weights != 0).any(0).to(torch.int32)  # [E_local]: some token routed here
             if self.fuse_act:
-                act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13)  # [E, T, I]
+                act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13, mask=mask)  # [E, T, I]
             else:
-                h13 = ops.awq_gemm_packed_batched(hidden_states, b13)  # [2E, T, I]
+                h13 = ops.awq_gemm_packed_batched(hidden_states, b13,
+                                                  mask=None if mask is None else mask.repeat(2))  # [2E, T, I]
                 act = F.silu(h13[:E]) * h13[E:]
-            y = ops.awq_gemm_packed_batched(act, b2)  # [E, T, H]
+            y = ops.awq_gemm_packed_batched(act, b2, mask=mask)  # [E, T, H]
             # each expert's output is scaled in fp32 and rounded to fp16 as `.mul_` does; the sum
             # over experts is taken in fp32 and rounded once
             scaled = (y.float() * expert_weights.t().unsqueeze(-1)).to(y.dtype)
