@@ -161,6 +161,8 @@ class MixtralMoE(torch.nn.Module):
             y = ops.awq_gemm_packed_batched(act, b2, mask=mask)  # [E, T, H]
             # each expert's output is scaled in fp32 and rounded to fp16 as `.mul_` does; the sum
             # over experts is taken in fp32 and rounded once
-            scaled = (y.float() * expert_weights.t().unsqueeze(-1)).to(y.dtype)
-            final = scaled.float().sum(0).to(y.dtype)
+            # (fp16 x fp32 promotes to an fp32 product; `sum(dtype=)` widens on load: same arithmetic as
+            # converting first, two launches fewer)
+            scaled = torch.mul(y, expert_weights.t().unsqueeze(-1)).to(y.dtype)
+            final = scaled.sum(0, dtype=torch.float32).to(y.dtype)
         return tensor_model_parallel_all_reduce(final).view(batch_size, sequence_length, hidden_dim)
