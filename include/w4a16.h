@@ -191,6 +191,8 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
  * is a DEVICE array of `batch` int32 (NULL = all on); problems whose entry is 0 are skipped and their
  * part of `out` is left as it was.  The mask is read by the kernel, not by the host, so it can be the
  * output of an earlier kernel on the same stream (no host synchronisation, HIP-graph capturable).
+ * `active_hint`: how many problems the caller expects to be on (0 = unknown); it only steers the
+ * launch shape, which is otherwise sized for `batch` busy problems.
  * For a mixture-of-experts block at a few tokens: only the experts some token was routed to are
  * read from memory, where the reference runs every local expert on every token and multiplies the
  * unselected ones by zero (vllm/model_executor/models/mixtral_quant.py:145-157).
@@ -198,7 +200,7 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
 int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const void* packed_w,
                                  const void* packed_sz, const void* bias, void* out,
                                  long long out_batch_stride, int M, int K, int N, int G, int batch,
-                                 int epilogue, const void* problem_mask, void* stream);
+                                 int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16

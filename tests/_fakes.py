@@ -37,7 +37,7 @@ class FakeOps:
         self.trace.append(["repack_batch", len(kernels)])
         return list(zip(kernels, scaling_factors, zeros))
 
-    def awq_gemm_packed_batched(self, x, packed, bias=None, mask=None):
+    def awq_gemm_packed_batched(self, x, packed, bias=None, mask=None, active_hint=0):
         self.trace.append(["awq_gemm_batched", list(x.shape), len(packed)] +
                           ([] if mask is None else [mask.tolist()]))
         outs = []
@@ -50,7 +50,7 @@ class FakeOps:
             outs.append(y if mask is None or int(mask[e]) else torch.zeros_like(y))  # skipped problems read as zero
         return torch.stack(outs)
 
-    def awq_gemm_packed_silu_and_mul(self, x, packed, bias=None, cfg=None, mask=None):
+    def awq_gemm_packed_silu_and_mul(self, x, packed, bias=None, cfg=None, mask=None, active_hint=0):
         self.trace.append(["awq_gemm_silu_and_mul", list(x.shape)] + ([] if mask is None else [mask.tolist()]))
         if isinstance(packed, list):  # a batch: list of (qweight, scales, qzeros)
             y = self.awq_gemm_packed_batched(x, packed, bias, mask=mask)

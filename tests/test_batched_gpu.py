@@ -154,9 +154,10 @@ def test_masked_batch_through_c_abi(L, cuda, M, epilogue):
                                          M * cols, M, K, N, G, E, epilogue, 0, 0, 0, 0, stream), "ex")
     for on in ([1, 0, 0, 1, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [0, 7, 0, 0, -1]):
         mask = torch.tensor(on, dtype=torch.int32, device=cuda)
+        hint = 0  # the hint may change the launch shape, hence the order of additions: compared without it
         out = torch.full((E, M, cols), 123.0, dtype=torch.float16, device=cuda)
         L.check(lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
-                                                 M * cols, M, K, N, G, E, epilogue, mask.data_ptr(), stream), "masked")
+                                                 M * cols, M, K, N, G, E, epilogue, mask.data_ptr(), hint, stream), "masked")
         torch.cuda.synchronize()
         for e in range(E):
             if on[e]:
@@ -166,11 +167,11 @@ def test_masked_batch_through_c_abi(L, cuda, M, epilogue):
     # no mask = every problem; a misaligned mask pointer is refused
     out = torch.empty((E, M, cols), dtype=torch.float16, device=cuda)
     L.check(lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
-                                             M * cols, M, K, N, G, E, epilogue, None, stream), "masked, no mask")
+                                             M * cols, M, K, N, G, E, epilogue, None, 0, stream), "masked, no mask")
     torch.cuda.synchronize()
     assert torch.equal(out, full)
     assert lib.w4a16_gemm_packed_f16_masked(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
-                                            M * cols, M, K, N, G, E, epilogue, mask.data_ptr() + 2, stream) == -6
+                                            M * cols, M, K, N, G, E, epilogue, mask.data_ptr() + 2, 0, stream) == -6
 
 
 def test_mixtral_block_skips_unselected_experts_on_gpu(cuda):

@@ -220,11 +220,13 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
                             packed: PackedAWQBatch,
                             bias: Optional[torch.Tensor] = None,
                             cfg: Optional[Tuple[int, ...]] = None,
-                            mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            mask: Optional[torch.Tensor] = None,
+                            active_hint: int = 0) -> torch.Tensor:
     """One launch for E GEMMs of one shape: in_feats [M, K] (shared by all problems) or [E, M, K] fp16,
     optional bias [E, N] -> [E, M, N] fp16.  Stands in for the reference's loop over experts
     (mixtral_quant.py:145-157).  `mask` (int32 [E] on the device, read by the kernel): problems whose entry
-    is 0 are skipped, their weights never read, and their rows of the result are zero."""
+    is 0 are skipped, their weights never read, and their rows of the result are zero; `active_hint` (how
+    many the caller expects to be on, 0 = unknown) steers the launch shape only."""
     _require(in_feats, torch.float16, "in_feats")
     E = packed.batch
     if in_feats.dim() == 2:
@@ -259,7 +261,7 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
                   packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M * packed.N, M, packed.K, packed.N,
                   packed.G, E)
         if mask is not None:
-            rc = lib.w4a16_gemm_packed_f16_masked(*common, EPI_NONE, mask.data_ptr(), _stream())
+            rc = lib.w4a16_gemm_packed_f16_masked(*common, EPI_NONE, mask.data_ptr(), int(active_hint), _stream())
         elif cfg is None:
             rc = lib.w4a16_gemm_packed_f16_batched(*common, _stream())
         else:  # (mt, t, waves) = streaming kernel, (mt, t, nw, kw) = LDS-staged kernel
@@ -276,7 +278,8 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
                                  packed,
                                  bias: Optional[torch.Tensor] = None,
                                  cfg: Optional[Tuple[int, ...]] = None,
-                                 mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                 mask: Optional[torch.Tensor] = None,
+                                 active_hint: int = 0) -> torch.Tensor:
     """silu(x @ W[:, :N/2]) * (x @ W[:, N/2:]) in one launch: the merged gate_up projection of a gated
     MLP with its activation fused into the GEMM epilogue (llama.py:74-80 of the reference runs the GEMM,
     then `silu_and_mul`).  `packed` is a PackedAWQ ([M, K] -> [M, N/2]) or a PackedAWQBatch ([M, K] shared
@@ -318,7 +321,7 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
         head = (x.data_ptr(), 0 if shared else M * packed.K, packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
                 bias_ptr, out.data_ptr(), M * half, M, packed.K, packed.N, packed.G, E, EPI_SILU_MUL)
         if mask is not None:
-            rc = lib.w4a16_gemm_packed_f16_masked(*head, mask.data_ptr(), _stream())
+            rc = lib.w4a16_gemm_packed_f16_masked(*head, mask.data_ptr(), int(active_hint), _stream())
         else:
             rc = lib.w4a16_gemm_packed_f16_ex(*head, mt, t, a, b, _stream())
         check(rc, "awq_gemm_silu_and_mul")

@@ -41,7 +41,7 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16_ex": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                  [c_int] * 10 + [c_void_p]),
     "w4a16_gemm_packed_f16_masked": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
-                                     [c_int] * 6 + [c_void_p, c_void_p]),
+                                     [c_int] * 6 + [c_void_p, c_int, c_void_p]),
     "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 

@@ -1390,7 +1390,7 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
                                const void* packed_sz, const void* bias, void* out,
                                long long out_batch_stride, int M, int K, int N, int G, int batch,
                                int epilogue, int mt, int t, int a_, int b_, void* stream,
-                               const void* problem_mask = nullptr) {
+                               const void* problem_mask = nullptr, int active_hint = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
   if (problem_mask && (reinterpret_cast<uintptr_t>(problem_mask) & 3u)) return W4A16_E_ALIGN;
   if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL && epilogue != W4A16_EPI_ADD_TO_OUT)
@@ -1413,7 +1413,9 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
   clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
   if (mt == 0) {
-    const Choice c = choose_cfg(M, K, N, batch, act);
+    // with a mask the launch shape is chosen for the problems expected to be on: the others cost nothing
+    const int busy = (problem_mask && active_hint > 0 && active_hint < batch) ? active_hint : batch;
+    const Choice c = choose_cfg(M, K, N, busy, act);
     mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
   }
   if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
@@ -1449,9 +1451,10 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
 int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const void* packed_w,
                                  const void* packed_sz, const void* bias, void* out,
                                  long long out_batch_stride, int M, int K, int N, int G, int batch,
-                                 int epilogue, const void* problem_mask, void* stream) {
+                                 int epilogue, const void* problem_mask, int active_hint, void* stream) {
+  if (active_hint < 0) return W4A16_E_SHAPE;
   return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
-                             N, G, batch, epilogue, 0, 0, 0, 0, stream, problem_mask);
+                             N, G, batch, epilogue, 0, 0, 0, 0, stream, problem_mask, active_hint);
 }
 
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,

@@ -149,16 +149,17 @@ class MixtralMoE(torch.nn.Module):
         else:
             b13, b2 = batches
             E = len(self.expert_indicies)
-            mask = None
+            mask, on = None, 0
             if hidden_states.shape[0] <= self.sparse_max_tokens:
                 mask = (expert_weights != 0).any(0).to(torch.int32)  # [E_local]: some token routed here
+                on = min(E, self.top_k * hidden_states.shape[0])  # at most; known without asking the device
             if self.fuse_act:
-                act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13, mask=mask)  # [E, T, I]
+                act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13, mask=mask, active_hint=on)  # [E, T, I]
             else:
-                h13 = ops.awq_gemm_packed_batched(hidden_states, b13,
-                                                  mask=None if mask is None else mask.repeat(2))  # [2E, T, I]
+                h13 = ops.awq_gemm_packed_batched(hidden_states, b13, mask=None if mask is None else mask.repeat(2),
+                                                  active_hint=2 * on)  # [2E, T, I]
                 act = F.silu(h13[:E]) * h13[E:]
-            y = ops.awq_gemm_packed_batched(act, b2, mask=mask)  # [E, T, H]
+            y = ops.awq_gemm_packed_batched(act, b2, mask=mask, active_hint=on)  # [E, T, H]
             # each expert's output is scaled in fp32 and rounded to fp16 as `.mul_` does; the sum
             # over experts is taken in fp32 and rounded once
             # (fp16 x fp32 promotes to an fp32 product; `sum(dtype=)` widens on load: same arithmetic as
