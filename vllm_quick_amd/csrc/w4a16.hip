@@ -197,6 +197,19 @@ __device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
   return a;
 }
 
+#ifdef W4A16_STAMPS
+// Diagnostic build only: per-wave cycle stamps of the GEMM kernels (never compiled into the
+// shipped library).  32 x 64-bit slots per wave.
+__device__ unsigned long long g_stamps[4096 * 32];
+#define STAMP(slot)                                                                      \
+  do {                                                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+    if (lane == 0) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (slot)] = t_;         \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 // MT : 16-row tiles of the output per workgroup
 // T  : 16-column tiles per workgroup
 // W  : wavefronts per workgroup (they split K)
@@ -224,6 +237,11 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   const int kq = lane >> 4;
   const int nt0 = blockIdx.x * H;
   const int m0 = blockIdx.y * (MT * 16);
+#ifdef W4A16_STAMPS
+  constexpr int NWAVES = W;
+  int n_done = 0;
+#endif
+  STAMP(0);
 
   const u32x4* wp[T];
   const uint32_t* szp[T];
@@ -360,18 +378,26 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       if constexpr (!XPRE) load_x(kb * 128, xf);
       load_block(kb, b0);
     }
+    STAMP(1);
     while (kb < a.KB) {
       int kn = kb + W;
       if (kn < a.KB) load_block(kn, b1);
       compute_block(kb, kn, b0, xf);
+#ifdef W4A16_STAMPS
+      STAMP(2 + min(n_done, 7)); ++n_done;
+#endif
       kb = kn;
       if (kb >= a.KB) break;
       kn = kb + W;
       if (kn < a.KB) load_block(kn, b0);
       compute_block(kb, kn, b1, xf);
+#ifdef W4A16_STAMPS
+      STAMP(2 + min(n_done, 7)); ++n_done;
+#endif
       kb = kn;
     }
   }
+  STAMP(10);
 
   // Cross-wave reduction through LDS: fold the upper half of the live waves onto the
   // lower half until LIVE partial sets fit the budget, then every wave sums whole tiles.
@@ -429,6 +455,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       for (int i = 0; i < TM; ++i) red[(w * TM + i) * 64 + lane] = acc[i / MT][i % MT];
     }
     __syncthreads();
+    STAMP(11);
     for (int i = w; i < OUTS; i += W) {
       f32x4 v = red[i * 64 + lane];
 #pragma unroll
@@ -443,6 +470,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       store_tile(i, v, vu);
     }
   }
+  STAMP(12);
 }
 
 // ---------------------------------------------------------------------------
@@ -460,18 +488,6 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
 // Load order per block iteration: next block's x share, then the weights two blocks ahead.
 // Vector-memory returns are counted in order, so this gives the L2-resident x one block and
 // the HBM weight stream two blocks of cover.
-#ifdef W4A16_STAMPS
-// Diagnostic build only: per-wave cycle stamps of the tiled kernel (never compiled into the
-// shipped library).  32 x 64-bit slots per wave.
-__device__ unsigned long long g_stamps[4096 * 32];
-#define STAMP(slot)                                                                      \
-  do {                                                                                   \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
-    if (lane == 0) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (slot)] = t_;         \
-  } while (0)
-#else
-#define STAMP(slot) do {} while (0)
-#endif
 
 // ACT (gate | up weight, silu(gate) * up stored, see gemm_packed_kernel): the first NW / 2 waves of a
 // K-group take the workgroup's gate columns, the others the matching up columns.
