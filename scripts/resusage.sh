@@ -1,5 +1,5 @@
 #!/bin/bash
-# Prints one line per kernel: name, VGPRs, AGPRs, scratch, occupancy.  Usage: tools_resusage.sh file.hip
+# Prints one line per kernel: name, VGPRs, AGPRs, scratch, occupancy.  Usage: scripts/resusage.sh file.hip
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -c -o /dev/null "$1" -Rpass-analysis=kernel-resource-usage 2>&1 \
  | grep -E "Function Name|    VGPRs:|AGPRs:|ScratchSize|Occupancy" \
  | sed -E 's/.*remark: //; s/ \[-Rpass.*//' | paste - - - - - \
