@@ -10,8 +10,10 @@ if len(sys.argv) > 2:
     K, N = int(sys.argv[1]), int(sys.argv[2])
 packs = [ops.awq_repack(*make_weights(K, N, G, i, dev)) for i in range(16)]
 cfgs = [None, (4, 2, 3, 4), (4, 3, 2, 4), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (4, 3, 4, 2), (2, 3, 2, 4), (2, 3, 1, 4),
-        (8, 3, 1, 2), (8, 3, 2, 2), (4, 6, 1, 4), (2, 6, 1, 4), (2, 3, 1, 8)]
-for M in (64, 128, 256, 512):
+        (8, 3, 1, 2), (8, 3, 2, 2), (4, 6, 1, 4), (2, 6, 1, 4), (2, 3, 1, 8),
+        # streaming kernel: (row tiles, column tiles, waves)
+        (4, 1, 8), (4, 2, 8), (4, 3, 8), (4, 4, 8), (2, 2, 8), (2, 3, 8), (2, 4, 8), (8, 1, 8), (8, 2, 8), (8, 3, 8), (4, 2, 4), (4, 3, 4)]
+for M in (48, 64, 128, 256, 512):
     x = make_x(M, K, 1, dev)
     res = []
     for cfg in cfgs:
@@ -22,4 +24,6 @@ for M in (64, 128, 256, 512):
             pass
     base = [u for u, c in res if c is None][0]
     res.sort()
+    import json
+    print("JSON " + json.dumps({"K": K, "N": N, "M": M, "us": {str(c): u for u, c in res}}), flush=True)
     print(f"{K}x{N} M={M}: default {base:.1f} us | " + "  ".join(f"{c}:{u:.1f}" for u, c in res[:6]), flush=True)

@@ -1247,11 +1247,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     const long long ctas = (long long)ceil_div(NT, nw * t) * ceil_div(mtiles, mt) * batch;
     // whole rounds of workgroups while they are few; with many rounds the partial last one fades
     const double rounds = ctas > 2 * cus ? (double)ctas / cus + 0.5 : (double)ceil_div(ctas, cus);
-    double cost = rounds * mt * t * nw;               // matrix work per workgroup
-    cost *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
-    cost *= (t == 3) ? 1.0 : 1.15;                    // x fragments re-used by 2 instead of 3 column tiles
-    cost *= (nw * kw == 8) ? 1.0 : 1.4;               // 4-wave workgroups: one wave per SIMD
-    cost *= 1.0 + 0.6 / nw;                           // x slab staged once per nw column waves
+    double work = mt * t * nw;                        // matrix work per workgroup, in output tiles
+    work *= (mt == 4) ? 1.0 : 1.45;                   // conversion shared by fewer MFMAs
+    work *= (t == 3) ? 1.0 : 1.15;                    // x fragments re-used by 2 instead of 3 column tiles
+    work *= (nw * kw == 8) ? 1.0 : 1.4;               // 4-wave workgroups: one wave per SIMD
+    work *= 1.0 + 0.6 / nw;                           // x slab staged once per nw column waves
+    // every round also pays a prologue, the cross-K-group reduction and the stores: about a third of a
+    // 24-tile workgroup's time.  Fitted on 11 layer shapes x 48-512 rows (scripts/exp_tiled_sweep.py):
+    // mean loss against the best built shape 1.5 % (2.4 % without this term).
+    const double cost = rounds * (work + 8.0);
     if (cost < best_cost) {
       best_cost = cost;
       best = Choice{true, mt, t, nw, kw};
