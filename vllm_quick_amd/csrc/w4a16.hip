@@ -1180,20 +1180,21 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
-  // 28-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
+  // 24-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
   // is long or the layer wide enough to amortise their prologue (11.9 vs 13.5 us on 4096 x 11008,
   // 20.7 vs 23.9 on 11008 x 4096; not on 4096 x 4096): x slabs arrive in whole cache lines instead of
   // 64-byte fragments.  With fewer rows the streaming kernel's fragment loads touch fewer lines and
   // it stays ahead.  Very wide layers (22016 columns) share each slab between two waves.
   const bool wide = (long long)NT * batch > 3 * cus;
-  const bool two_tiles_staged = mtiles == 2 && (wide || (M >= 28 && (KB >= 64 || NT >= 512))) && KB >= 16 &&
+  const bool two_tiles_staged = mtiles == 2 && (wide || (M >= 24 && (KB >= 64 || NT >= 512))) && KB >= 16 &&
                                 (!act || wide);  // fused activation: built for even NW only
   if (mtiles <= 2 && !two_tiles_staged) {
     const int MT = mtiles;
     int Wv = (MT == 1) ? 16 : 8;
     while (Wv > 4 && Wv > pow2_floor(KB)) Wv /= 2;
-    // one or two rows over a long K (11008): 8 waves with four blocks each in flight beat 16 (8.8 vs 9.6 us)
-    if (M <= 2 && KB >= 64 && Wv == 16) Wv = 8;
+    // one or two rows over a very long K (14336): 8 waves with four blocks each in flight beat 16
+    // (10.2 vs 10.4 us); up to K = 11008 it is the other way round (8.5 vs 8.8 us)
+    if (M <= 2 && KB >= 100 && Wv == 16) Wv = 8;
     // Many tiles (batched launches, very wide layers): workgroups run back to back on a CU, and
     // small ones, several to a CU, overlap one's loads with another's arithmetic and reduction -
     // 5.4 TB/s of weights at 1-16 rows against 3.9 for one 16-wave workgroup per CU.
@@ -1204,7 +1205,20 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
       // More than three tiles per CU (a 22016-wide gate_up layer): 16-wave workgroups of 3 tiles would
       // run in two uneven rounds; 8-wave workgroups are all resident at once (12.6 vs 14.3 us at
       // 1 row, 13.8 vs 16.3 us at 16 rows on 4096 x 22016).
-      if (!act && tiles > 3 * cus) return Choice{false, 1, M <= 8 ? 3 : 6, 8, 0};
+      // Among 2, 3, 4 and 6 tiles per workgroup the one that leaves the busiest CU the fewest tiles
+      // (896 tiles, a 14336-wide layer: 4 with T = 2 or 4, 6 with T = 3; 9.2 vs 11.8 us at 1 row); few
+      // rows prefer small workgroups, 9-16 rows large ones (their x fragments serve more tiles).
+      if (!act && tiles > 3 * cus) {
+        static const int few[4] = {3, 2, 4, 6}, many[4] = {6, 4, 3, 2};
+        const int* order = M <= 8 ? few : many;
+        int best_t = order[0];
+        long long best_load = -1;
+        for (int i = 0; i < 4; ++i) {
+          const long long load = ceil_div(ceil_div(tiles, order[i]), cus) * order[i];
+          if (best_load < 0 || load < best_load) best_load = load, best_t = order[i];
+        }
+        return Choice{false, 1, best_t, 8, 0};
+      }
     }
     if (act) {
       // gate/up tile pairs: an even T from the fused-activation instantiations
