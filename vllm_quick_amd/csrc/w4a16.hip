@@ -1200,8 +1200,12 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
     // 5.4 TB/s of weights at 1-16 rows against 3.9 for one 16-wave workgroup per CU.
     const long long tiles = (long long)NT * batch;
     if (MT == 1 && KB >= 8) {
-      if (tiles >= 16 * cus) return Choice{false, 1, 4, 4, 0};
-      if (tiles >= 6 * cus) return Choice{false, 1, 2, 8, 0};
+      // From six tiles per CU on, the more rows the more tiles per workgroup (a wave's x fragments then
+      // serve more of them): 8192 x 57344 with the fused activation 46 / 51 / 53 us at 1 / 8 / 16 rows,
+      // against 50 / 54 / 70 with two tiles and eight waves throughout.
+      if (act && tiles >= 6 * cus && M > 8) return Choice{false, 1, 8, 8, 0};  // measured with the fused activation only
+      if (tiles >= 16 * cus || (tiles >= 6 * cus && M > 4)) return Choice{false, 1, 4, 4, 0};
+      if (tiles >= 6 * cus) return Choice{false, 1, 2, 4, 0};
       // More than three tiles per CU (a 22016-wide gate_up layer): 16-wave workgroups of 3 tiles would
       // run in two uneven rounds; 8-wave workgroups are all resident at once (12.6 vs 14.3 us at
       // 1 row, 13.8 vs 16.3 us at 16 rows on 4096 x 22016).
