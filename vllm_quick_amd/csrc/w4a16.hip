@@ -1247,6 +1247,12 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   // 65-128 rows on a layer of at most 256 column tiles (4096 columns): 64 x 4 = 256 workgroups of the
   // streaming kernel (2 row tiles x 4 column tiles, 8 waves) fill the chip exactly and beat the
   // LDS-staged shapes by ~10 % (13.6 vs 15.0 us on 4096 x 4096, 30.2 vs 33.3 on 11008 x 4096).
+  // 33-64 rows on a layer of 448-512 column tiles: two row-blocks of the same shape fill the chip in one round
+  // (1024 x 8192: 5.5-5.9 us against 6.4-6.6 for the best LDS-staged shape; 8192 x 7168: 23.2 against 24.4).
+  if (!act && mtiles >= 3 && mtiles <= 4 && KB >= 8) {
+    const long long wgs = (long long)ceil_div((long long)NT * batch, 4) * 2;
+    if (wgs <= cus && wgs * 8 >= cus * 7) return Choice{false, 2, 4, 8, 0};
+  }
   if (!act && mtiles > 4 && mtiles <= 8 && (long long)NT * batch <= cus && (long long)NT * batch * 8 >= cus * 7 && KB >= 16)
     return Choice{false, 2, 4, 8, 0};
   if (two_tiles_staged) {
