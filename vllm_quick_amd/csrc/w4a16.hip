@@ -1182,11 +1182,11 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int cus = 256;
   // 24-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
   // is long or the layer wide enough to amortise their prologue (11.9 vs 13.5 us on 4096 x 11008,
-  // 20.7 vs 23.9 on 11008 x 4096; not on 4096 x 4096): x slabs arrive in whole cache lines instead of
-  // 64-byte fragments.  With fewer rows the streaming kernel's fragment loads touch fewer lines and
+  // 20.7 vs 23.9 on 11008 x 4096; on 4096 x 4096 from 30 rows only: 9.8 vs 10.3 at 32): x slabs arrive
+  // in whole cache lines instead of 64-byte fragments.  With fewer rows the streaming kernel's fragment loads touch fewer lines and
   // it stays ahead.  Very wide layers (22016 columns) share each slab between two waves.
   const bool wide = (long long)NT * batch > 3 * cus;
-  const bool two_tiles_staged = mtiles == 2 && (wide || (M >= 24 && (KB >= 64 || NT >= 512))) && KB >= 16 &&
+  const bool two_tiles_staged = mtiles == 2 && (wide || (M >= 24 && (KB >= 64 || NT >= 512)) || (M >= 30 && KB >= 32 && NT >= 256)) && KB >= 16 &&
                                 (!act || wide);  // fused activation: built for even NW only
   if (mtiles <= 2 && !two_tiles_staged) {
     const int MT = mtiles;
