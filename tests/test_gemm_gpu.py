@@ -254,6 +254,24 @@ def test_down_proj_shape_parity(abi, cuda, M):
     assert_parity(y, faithful, exact, strict=False, what=f"down_proj M={M}", max_frac=5e-4)
 
 
+@pytest.mark.parametrize("K,N,M", [
+    (1024, 14336, 4), (1024, 14336, 12),    # 769-1535 column tiles: tiles per workgroup by the busiest CU's load
+    (1024, 24576, 2), (1024, 24576, 6), (1024, 24576, 12),  # six tiles per CU and more
+    (1024, 8192, 48), (1024, 7168, 64),     # 33-64 rows on 448-512 column tiles: streaming shape in one round
+    (4096, 4096, 31),                       # LDS-staged two-row-tile shape on a 256-tile layer
+    (14336, 256, 2),                        # one or two rows over a very long K
+])
+def test_default_launch_shape_branches_parity(abi, cuda, K, N, M):
+    """The default launch (no shape given) on layers that take the less common branches of the launch-shape
+    choice: each must dispatch a built kernel and give the same result as everywhere else."""
+    G = 128
+    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=3000 + M + N)
+    faithful, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
+    packed = abi.repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
+    y = abi.gemm_packed(dev_t(x, cuda), packed).cpu().numpy()
+    assert_parity(y, faithful, exact, strict=False, what=f"{K}x{N} M={M}", max_frac=5e-4)
+
+
 def test_full_size_dequantize_bit_exact(abi, full):
     assert (bits(abi.dequant(full["tqw"], full["ts"], full["tqz"]).cpu().numpy()) == bits(full["w"])).all()
     assert (bits(abi.dequant_packed(full["packed"]).cpu().numpy()) == bits(full["w"])).all()
