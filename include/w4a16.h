@@ -135,6 +135,18 @@ int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const v
                                     int t, int nw, int kw, void* stream);
 
 /*
+ * The variant built on 32x32x16 matrix instructions, with an explicit launch shape, for tuning and
+ * tests (w4a16_gemm_packed_f16 picks it by itself when it is the faster one): a workgroup owns
+ * mt x t tiles of 32 rows x 32 columns; its kw wavefronts split K and each stages the activations of
+ * its own K blocks in a private piece of LDS (no barrier in the main loop).  Built combinations only;
+ * others return W4A16_E_SHAPE.  In the `_cfg` / `_ex` entry points below this kernel is selected by
+ * (mt, t, a = 1, b = -kw).
+ */
+int w4a16_gemm_packed_f16_wide_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                                   const void* bias, void* out, int M, int K, int N, int G, int mt,
+                                   int t, int kw, void* stream);
+
+/*
  * `batch` independent GEMMs of one shape in a single launch: problem b computes
  *   out + b * out_batch_stride  =  (x + b * x_batch_stride) @ W_b  (+ bias + b * N)
  * with W_b at packed_w + b * w4a16_packed_weight_bytes(K, N) and packed_sz +

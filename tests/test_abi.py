@@ -76,3 +76,19 @@ def test_argument_errors_return_codes_without_launching(lib):
         lib.check(-1, "x")
     with pytest.raises(RuntimeError):
         lib.check(-7, "x")
+
+
+def test_native_binding_module_loads_and_mirrors_the_reference_ops():
+    """The compiled pybind11 module imports without a GPU and exposes `ops.awq_gemm` / `ops.awq_dequantize`
+    with the reference's positional signatures (csrc/pybind.cpp:52-55, csrc/ops.h:69-82)."""
+    from vllm_quick_amd import _C_native, _lib
+    assert _C_native.abi_version() == _lib.ABI_VERSION
+    assert "arg4" in _C_native.ops.awq_gemm.__doc__ and "arg5" not in _C_native.ops.awq_gemm.__doc__
+    assert "arg5" in _C_native.ops.awq_dequantize.__doc__ and "arg6" not in _C_native.ops.awq_dequantize.__doc__
+    assert _C_native.stock_kernel_calls() == 0
+    import torch
+    x = torch.zeros((1, 32), dtype=torch.float16)
+    import pytest
+    with pytest.raises(RuntimeError, match="GPU"):  # no CPU implementation, as the package's own ops module
+        _C_native.ops.awq_gemm(x, torch.zeros((32, 1), dtype=torch.int32), torch.zeros((1, 8), dtype=torch.float16),
+                               torch.zeros((1, 1), dtype=torch.int32), 8)

@@ -82,6 +82,9 @@ class CABI:
         if cfg is None:
             rc = self.lib.w4a16_gemm_packed_f16(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b, out.data_ptr(), M, K, N,
                                                 G, self.stream())
+        elif cfg[0] == "wide":
+            rc = self.lib.w4a16_gemm_packed_f16_wide_cfg(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b, out.data_ptr(),
+                                                         M, K, N, G, cfg[1], cfg[2], cfg[3], self.stream())
         elif len(cfg) == 4:
             rc = self.lib.w4a16_gemm_packed_f16_tiled_cfg(x.data_ptr(), pw.data_ptr(), ps.data_ptr(), b,
                                                           out.data_ptr(), M, K, N, G, cfg[0], cfg[1], cfg[2], cfg[3],
@@ -170,7 +173,10 @@ CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 8), (1, 6, 8), (1, 1, 8), (1,
         (4, 3, 4), (8, 1, 8), (8, 3, 8), (8, 1, 4), (8, 3, 4),
         # LDS-staged kernel: (mt, t, nw, kw)
         (4, 3, 2, 4), (4, 3, 4, 2), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (2, 3, 2, 4), (2, 3, 1, 4),
-        (8, 3, 2, 2), (8, 3, 1, 2), (4, 6, 1, 4), (2, 6, 1, 4)]
+        (8, 3, 2, 2), (8, 3, 1, 2), (4, 6, 1, 4), (2, 6, 1, 4),
+        # 32x32x16 kernel: ("wide", mt, t, kw)
+        ("wide", 2, 3, 8), ("wide", 2, 2, 8), ("wide", 2, 1, 8), ("wide", 1, 3, 8), ("wide", 1, 2, 8),
+        ("wide", 2, 3, 4), ("wide", 2, 2, 4), ("wide", 1, 3, 4)]
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
@@ -258,6 +264,22 @@ def test_default_launch_shape_branches_parity(abi, cuda, K, N, M):
     packed = abi.repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
     y = abi.gemm_packed(dev_t(x, cuda), packed).cpu().numpy()
     assert_parity_slack(y, *reference_arithmetic(x, orc.dequantize(qw, s, qz)), what=f"{K}x{N} M={M}")
+
+
+@pytest.mark.parametrize("cfg", [("wide", 2, 3, 8), ("wide", 1, 3, 8), ("wide", 2, 2, 4)])
+def test_full_size_wide_kernel(abi, cuda, full, cfg):
+    """The 32x32x16 kernel at 4096 x 11008: oracle parity at 100 (ragged) rows, and unit rows x = e_k,
+    which must return rows of the dequantised weights bit for bit (the whole k <-> lane <-> word mapping
+    of its reading of the packed layout)."""
+    x = orc.make_inputs(100, full["K"], full["N"], full["G"], seed=4100)[0]
+    y = abi.gemm_packed(dev_t(x, cuda), full["packed"], cfg=cfg).cpu().numpy()
+    assert_parity_slack(y, *reference_arithmetic(x, full["w"]), what=f"wide {cfg}")
+    ks = [0, 1, 7, 8, 15, 16, 31, 32, 63, 64, 127, 128, 2047, 4095, 1234, 3210, 999, 65, 4000] + list(range(512, 545))
+    xe = np.zeros((len(ks), full["K"]), np.float16)
+    for i, k in enumerate(ks):
+        xe[i, k] = 1.0
+    ye = abi.gemm_packed(dev_t(xe, cuda), full["packed"], cfg=cfg).cpu().numpy()
+    assert (bits(ye) == bits(full["w"][ks])).all()
 
 
 def test_full_size_dequantize_bit_exact(abi, full):

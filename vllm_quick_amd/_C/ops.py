@@ -124,7 +124,7 @@ def awq_gemm_packed(in_feats: torch.Tensor,
                     packed: PackedAWQ,
                     bias: Optional[torch.Tensor] = None,
                     cfg: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
-    """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves), or (mt, t, nw, kw) for the LDS-staged kernel, overrides the launch shape."""
+    """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves), (mt, t, nw, kw) for the LDS-staged kernel or ("wide", mt, t, kw) for the 32x32x16 kernel overrides the launch shape."""
     _require(in_feats, torch.float16, "in_feats")
     if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
         raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
@@ -146,6 +146,11 @@ def awq_gemm_packed(in_feats: torch.Tensor,
         if cfg is None:
             rc = lib.w4a16_gemm_packed_f16(x.data_ptr(), packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
                                            bias_ptr, out.data_ptr(), M, packed.K, packed.N, packed.G, _stream())
+        elif cfg[0] == "wide":  # the 32x32x16 kernel: ("wide", mt, t, kw), tiles of 32 rows / 32 columns
+            _, mt, t, kw = cfg
+            rc = lib.w4a16_gemm_packed_f16_wide_cfg(x.data_ptr(), packed.packed_w.data_ptr(),
+                                                    packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M,
+                                                    packed.K, packed.N, packed.G, mt, t, kw, _stream())
         elif len(cfg) == 4:
             mt, t, nw, kw = cfg
             rc = lib.w4a16_gemm_packed_f16_tiled_cfg(x.data_ptr(), packed.packed_w.data_ptr(),

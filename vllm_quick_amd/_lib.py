@@ -34,6 +34,7 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "w4a16_gemm_packed_f16_cfg": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "w4a16_gemm_packed_f16_tiled_cfg": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "w4a16_gemm_packed_f16_wide_cfg": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "w4a16_gemm_packed_f16_batched": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 +
                                       [ctypes.c_longlong] + [c_int] * 5 + [c_void_p]),
     "w4a16_gemm_packed_f16_batched_cfg": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 +

@@ -48,6 +48,12 @@
 #ifndef W4A16_DEEP_TM
 #define W4A16_DEEP_TM 1
 #endif
+#ifndef W4A16_HEAD
+#define W4A16_HEAD 1
+#endif
+#ifndef W4A16_ILV
+#define W4A16_ILV 1  // the 32x32x16 kernel deals matrix and conversion instructions out alternately
+#endif
 
 namespace {
 
@@ -56,6 +62,7 @@ typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -201,10 +208,11 @@ __device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
 // Diagnostic build only: per-wave cycle stamps of the GEMM kernels (never compiled into the
 // shipped library).  32 x 64-bit slots per wave.
 __device__ unsigned long long g_stamps[4096 * 32];
+#define STAMP_OK ((size_t)blockIdx.x * NWAVES + w < 4096)  /* larger grids: only the first 4096 waves are stamped */
 #define STAMP(slot)                                                                      \
   do {                                                                                   \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
-    if (lane == 0) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (slot)] = t_;         \
+    if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + (slot)] = t_; \
   } while (0)
 #else
 #define STAMP(slot) do {} while (0)
@@ -674,7 +682,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
     const unsigned long long tc = __builtin_amdgcn_s_memtime();
     t_work += tb - ta;
     t_bar += tc - tb;
-    if (lane == 0 && i < 8) {
+    if (lane == 0 && i < 8 && STAMP_OK) {
       g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 8 + 2 * i] = tb - ta;
       g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 9 + 2 * i] = tc - tb;
     }
@@ -708,7 +716,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
   STAMP(2);
 #ifdef W4A16_STAMPS
-  if (lane == 0) {
+  if (lane == 0 && STAMP_OK) {
     g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 5] = t_work;
     g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 6] = t_bar;
     g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -763,6 +771,329 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
     finish_tile(o, v, vu);
   }
   STAMP(4);
+}
+
+// ---------------------------------------------------------------------------
+// GEMM on the private layout with 32x32x16 matrix instructions (M > 32)
+// ---------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16 does twice the work of the 16x16x32 form per instruction and per converted
+// weight word, which halves the int4 -> fp16 conversion's share of the vector issue slots.  Its A
+// operand wants lane l to hold 8 k of weight column l & 31, k-octet l >> 5 of a 16-k step.  The packed
+// layout (16-column tiles, lane quads of four 32-k words) serves it as it is: lanes with bit 4 clear
+// read the even 16-column tile of the pair, the others the odd one, from source lanes
+// (l & 15) + 16 (2 s + (l >> 5)), s = 0, 1: two 16-byte loads per lane and 128-k block, word j of load
+// s being the fragment of k-step 2 j + s (k = 128 kb + 32 j + 16 s + 8 (l >> 5) + i).
+//
+// A workgroup owns MT x T tiles of 32 x 32 outputs over the whole of K; its KW waves split K (wave w
+// takes blocks w, w + KW, ...) and each holds all MT x T accumulator tiles.  A wave keeps the
+// [32 MT rows] x [128 k] activation slab of its current block in a PRIVATE piece of LDS: two halves of
+// 64 k, each row of a half 128 bytes with its 16-byte chunks XOR-swizzled by the row.  The halves are
+// filled by LDS-DMA loads (global -> LDS with no register in between; the swizzle is applied to the
+// source address, since a DMA instruction writes 1 KiB of LDS in lane order): as soon as the k-steps of
+// a half are done, the same half of the wave's NEXT block is requested into it and has the other
+// half's k-steps to arrive.  No other wave touches that LDS, so the main loop has no barrier; the
+// DMA's completion is awaited with counted s_waitcnt vmcnt (vector-memory operations of a wave complete
+// in issue order; the compiler does not track data that arrives in LDS this way).
+template <bool V>
+struct Flag {
+  static constexpr bool value = V;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MT, int T, int KW, int SZS>
+__global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_blocks, int panel_rows,
+                                                            const GemmArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  fetch_args_now(ga);
+  asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
+  const GemmArgs a = batch_slice(ga);
+  constexpr int R = MT * 32;             // rows of the workgroup's tile
+  constexpr int HALF = R * 128;          // bytes of a half slab: R rows x 64 k
+  constexpr int SLAB = 2 * HALF;
+  constexpr int XLR = R / 8;             // DMA loads per half slab (8 rows x 128 bytes each)
+  constexpr int XL = (W4A16_DBG & 1) ? 1 : XLR;
+  constexpr int NSZ = 4 / SZS;           // scale/zero words per 128-k block and tile
+  constexpr int WL = T * (NSZ + 2);      // register loads per weight block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+#ifdef W4A16_STAMPS
+  constexpr int NWAVES = KW;
+  int n_done = 0;
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
+  STAMP(0);
+
+  // workgroup id -> (column slice, row block): row blocks of a slice share an XCD (ids 8 apart), in
+  // panels once there are more than 8 of them (as gemm_tiled_kernel)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
+  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
+  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
+  const int slice = (in_panel / rows_here) * 8 + xcd;
+  const int mb = panel * panel_rows + in_panel % rows_here;
+  if (slice >= n_slices) return;  // whole workgroup
+  const int ct0 = slice * T;      // first 32-column tile
+  const int m0 = mb * R;
+
+  // Per-lane byte offsets from the (uniform) buffer bases: 32 bits each (the host checks the sizes).
+  uint32_t woff[T], szoff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    // 16-column tiles past the end re-read the last one (valid memory); their results are dropped
+    const int t16 = min(2 * (ct0 + t) + ((lane >> 4) & 1), a.NT - 1);
+    woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
+    szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
+  }
+  // DMA p of a half slab fills rows 8 p .. 8 p + 7: lane -> row 8 p + (lane >> 3), 16-byte position
+  // lane & 7, which holds chunk (lane & 7) ^ ((row >> 1) & 7) of the row's 64 k
+  uint32_t xoff[XLR];
+  int xchunk[2];  // chunk index fetched by this lane, p even / odd
+#pragma unroll
+  for (int e = 0; e < 2; ++e) xchunk[e] = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);
+#pragma unroll
+  for (int p = 0; p < XLR; ++p)
+    xoff[p] = ((uint32_t)min(m0 + 8 * p + (lane >> 3), a.M - 1) * a.K + xchunk[p & 1] * 8) * 2u;
+  const int wbase = w * SLAB;
+  // B fragment of k-step ks (0..3) of a half: row r32 (+ 32 mt), chunk 2 ks + h
+  int xrd[4];
+  {
+    const int f = (r32 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xrd[ks] = wbase + r32 * 128 + (((2 * ks + h) ^ f) << 4);
+  }
+
+  f32x16 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  const DqConst dqc = make_dq_const();
+
+  struct WSet {
+    uint32_t sz[T][NSZ];
+    u32x4 q[T][2];
+  };
+  // Buffer-addressed loads throughout: descriptor base + 32-bit lane offset + scalar offset costs no
+  // vector arithmetic per load, and (unlike the global_load ... lds form, which the compiler treats as a
+  // flat access that forces every later wait to zero) the LDS-DMA variant keeps the compiler's own wait
+  // counts for the weight registers exact.
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  auto load_w = [&](int kb, WSet& b) {
+    if (W4A16_DBG & 2) kb = w;  // ablation: weights from cache
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
+      b.q[t][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + 512, kb * 1024, 0);
+    }
+  };
+  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
+  auto dma_x = [&](int kb, int hp) {
+#pragma unroll
+    for (int p = 0; p < XL; ++p)  // (ablation 1: XL is 1, an eighth of the activation traffic)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + wbase + hp * HALF + p * 1024), 16, xoff[p],
+          (kb * 128 + hp * 64) * 2, 0, 0);
+  };
+  // B fragments of k-step `kstep` (0..7) of the block: 2 ds_read_b128 from half kstep / 4
+  auto read_x = [&](int kstep, f16x8 (&xf)[MT]) {
+    const int hp = kstep >> 2, ks = kstep & 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + hp * HALF + mt * 4096);
+  };
+  // The weight fragment of tile t at k-step `kstep` (scale/zero constants refreshed where a new group starts)
+  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+    if (W4A16_DBG & 4) return __builtin_bit_cast(f16x8, b.q[t][kstep & 1]);  // ablation: no conversion
+    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+  };
+  // One k-step: MT x T matrix instructions.  The conversion runs ONE TILE AHEAD of them (`af0` comes in
+  // converted; tiles 1.. and tile 0 of the next k-step are converted here), and the two instruction kinds
+  // are dealt out alternately: a wave issues in order, so a matrix instruction that finds the pipe still
+  // busy with its predecessor would otherwise hold back the ~52 cycles of conversion behind it, and a
+  // single wave would run at half the matrix rate.
+  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
+    f16x8 af[T + 1];
+    af[0] = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T)
+        af[t + 1] = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        af[T] = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+    }
+    if (kstep + 1 < 8) af0 = af[T];
+    if (W4A16_ILV) {
+      constexpr int per = (13 + MT - 1) / MT;  // vector instructions of one conversion per matrix instruction
+#pragma unroll
+      for (int i = 0; i < T * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one matrix instruction
+        __builtin_amdgcn_sched_group_barrier(0x002, per, 0);  // a share of the next conversion
+      }
+    }
+  };
+  // One 128-k block from weight set `cur`.  With PF the wave's next block is requested meanwhile: its
+  // weights into `nxt` at the start, each half of its slab into the LDS half just consumed.  A wave's
+  // vector-memory operations, in issue order, are thus
+  //   W(0), D0(0), D1(0), W(1), D0(1), D1(1), W(2), ..          (D = XL DMA loads, W = WL loads)
+  // Half 0 of block i is read from the start of the block: all but the XL + WL youngest must be done
+  // (XL in the last block, which requests nothing).  Half 1 is first read during k-step 3 (fragments
+  // are fetched one k-step ahead), before D0(i+1) is issued: all but the WL youngest (none in the last
+  // block).  A half is overwritten only after the matrix instructions of its last k-step were issued,
+  // i.e. after its last read returned.
+  auto block = [&](auto pf, int kb_next, const WSet& cur, WSet& nxt) {
+    constexpr bool PF = decltype(pf)::value;
+    SZ c[T];
+    f16x8 xa[MT], xb[MT];
+    if constexpr (PF) {
+      load_w(kb_next, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_vmcnt<PF ? XL + WL : XL>();
+    read_x(0, xa);
+    f16x8 af0 = convert(0, 0, cur, c);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      // even k-step on xa while xb arrives, odd k-step on xb while xa arrives
+      read_x(k2 + 1, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2, cur, c, xa, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 + 1 == 3) wait_vmcnt<PF ? WL : 0>();
+      if (k2 + 2 < 8) read_x(k2 + 2, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2 + 1, cur, c, xb, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PF) {
+        if (k2 + 1 == 3) dma_x(kb_next, 0);
+        if (k2 + 1 == 7) dma_x(kb_next, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef W4A16_STAMPS
+    STAMP(2 + min(n_done, 15));
+    ++n_done;
+#endif
+  };
+
+  // This wave's blocks.  With 8 waves the second wave of each SIMD gets its first requests out several
+  // thousand cycles after the first (the CU's memory path takes a workgroup's cold first round at a
+  // fraction of its steady rate) and would finish that much later; so the first four waves take a head
+  // start of two blocks each: blocks 0-7 go to waves 0-3 (w, w + 4), the rest round-robin over all eight
+  // (wave w: 8 + w, 16 + w, ..).  `next` steps through a wave's list.
+  // Blocks with a successor go two per trip (the weight sets swap roles, nothing in the loop body is
+  // conditional: a branch there makes the compiler's own wait counts collapse to "everything"); an odd
+  // one out hands its prefetched set over by register copy, so that the last block always reads `w0`
+  // and the accumulators never meet from two paths.
+  constexpr bool HEAD = (KW == 8) && W4A16_HEAD;
+  auto next = [&](int kb) { return (HEAD && kb < 8) ? kb + 4 : kb + KW; };
+  int kb = (HEAD && w >= 4) ? 8 + w : w;
+  int nblk = 0;
+  for (int b = kb; b < a.KB; b = next(b)) ++nblk;
+  if (nblk > 0) {
+    WSet w0, w1;
+    load_w(kb, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_x(kb, 0);
+    dma_x(kb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    int i = 0;
+    for (; i + 2 < nblk; i += 2) {
+      const int k1 = next(kb), k2 = next(k1);
+      block(Flag<true>{}, k1, w0, w1);
+      block(Flag<true>{}, k2, w1, w0);
+      kb = k2;
+    }
+    if (i + 1 < nblk) {
+      kb = next(kb);
+      block(Flag<true>{}, kb, w0, w1);
+      w0 = w1;
+    }
+    block(Flag<false>{}, kb, w0, w1);
+  }
+
+  // Cross-wave reduction through LDS (the slabs are free once every wave is past this barrier).  A
+  // wave's partial result is T * MT * 4 slices of 1 KiB: 4 accumulator registers x 64 lanes, i.e. for
+  // tile (t, mt) and register group q the outputs of token 32 mt + r32, columns 32 t + 8 q + 4 h .. + 3.
+  // With 8 waves the upper four first park theirs, the lower four add them in place; then every wave
+  // sums the remaining sets for its share of the slices and stores.
+  constexpr int NSL = T * MT * 4;
+  constexpr int LIVE = KW > 4 ? KW / 2 : KW;
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+  auto part = [&](int i) {
+    const int t = i / (MT * 4), mt = (i >> 2) % MT, q = i & 3;
+    return f32x4{acc[t][mt][4 * q], acc[t][mt][4 * q + 1], acc[t][mt][4 * q + 2], acc[t][mt][4 * q + 3]};
+  };
+  STAMP(20);
+  __syncthreads();
+  STAMP(21);
+  if constexpr (KW > LIVE) {
+    if (w >= LIVE) {
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) red[((w - LIVE) * NSL + i) * 64 + lane] = part(i);
+    }
+    __syncthreads();
+    if (w < LIVE) {
+      // all reads first, then the sums back in place: one dependent round trip, not NSL of them
+      f32x4 other[NSL];
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) other[i] = red[(w * NSL + i) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) red[(w * NSL + i) * 64 + lane] = other[i] + part(i);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) red[(w * NSL + i) * 64 + lane] = part(i);
+  }
+  __syncthreads();
+  STAMP(22);
+  for (int i = w; i < NSL; i += KW) {
+    f32x4 v = red[i * 64 + lane];
+#pragma unroll
+    for (int s = 1; s < LIVE; ++s) v += red[(s * NSL + i) * 64 + lane];
+    const int t = i / (MT * 4), mt = (i >> 2) % MT, q = i & 3;
+    const int n = (ct0 + t) * 32 + 8 * q + 4 * h;
+    const int m = m0 + mt * 32 + r32;
+    if (m < a.M && n < a.N) {
+      f16x4 hv = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+      if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + n);
+      f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+      if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+      *dst = hv;
+    }
+  }
+  STAMP(23);
+#ifdef W4A16_STAMPS
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1134,6 +1465,49 @@ int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t
   return W4A16_E_SHAPE;
 }
 
+template <int MT, int T, int KW>
+int launch_wide(const GemmArgs& a, hipStream_t s, int batch) {
+  constexpr int stage = KW * MT * 32 * 256;  // one private slab per wave
+  constexpr int reduce = (KW > 4 ? KW / 2 : KW) * T * MT * 4 * 1024;     // partial tiles
+  constexpr int lds = stage > reduce ? stage : reduce;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  // whole 128-k blocks only, and 32-bit byte offsets into the three buffers
+  if (a.K % 128 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31)) return W4A16_E_SHAPE;
+  const int n_slices = ceil_div(ceil_div(a.N, 32), T);
+  const int m_blocks = ceil_div(a.M, MT * 32);
+  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  void (*kern)(int, int, int, const GemmArgs) = nullptr;
+  if (a.G % 128 == 0)
+    kern = gemm_wide_kernel<MT, T, KW, 4>;
+  else if (a.G == 64)
+    kern = gemm_wide_kernel<MT, T, KW, 2>;
+  else
+    kern = gemm_wide_kernel<MT, T, KW, 1>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+  }
+  const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * KW), lds, s, n_slices, m_blocks, panel_rows, a);
+  return launched();
+}
+
+// (mt, t, kw) of the 32x32x16 kernel: mt, t in 32-row / 32-column tiles
+#define W4A16_FOR_EACH_WIDE(X) \
+  X(2, 3, 8) X(2, 2, 8) X(2, 1, 8) X(1, 3, 8) X(1, 2, 8) X(2, 3, 4) X(2, 2, 4) X(1, 3, 4)
+
+int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch = 1) {
+#define X(MT_, T_, KW_) \
+  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch);
+  W4A16_FOR_EACH_WIDE(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
 // (mt, t, waves) -> instantiation.  mt in {1,2,4,8}; t in 1..8 with mt*t <= 24;
 // waves 16 for mt <= 2 (128 VGPRs/lane are enough), 8 for mt >= 4; plus 4/8 for short K.
 #define W4A16_FOR_EACH_CFG(X) \
@@ -1418,6 +1792,16 @@ int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const v
   return dispatch_tiled(a, mt, t, nw, kw, static_cast<hipStream_t>(stream));
 }
 
+int w4a16_gemm_packed_f16_wide_cfg(const void* x, const void* packed_w, const void* packed_sz,
+                                   const void* bias, void* out, int M, int K, int N, int G, int mt,
+                                   int t, int kw, void* stream) {
+  GemmArgs a;
+  const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
+  if (rc) return rc;
+  clear_stale_error();
+  return dispatch_wide(a, mt, t, kw, static_cast<hipStream_t>(stream));
+}
+
 int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
                           const void* bias, void* out, int M, int K, int N, int G, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0) return W4A16_E_SHAPE;
@@ -1462,6 +1846,7 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
     const Choice c = choose_cfg(M, K, N, busy, act);
     mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
   }
+  if (b_ < 0) return act ? W4A16_E_SHAPE : dispatch_wide(a, mt, t, -b_, s, batch);
   if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
   return dispatch_packed(a, mt, t, a_, s, batch, act);
 }
