@@ -147,9 +147,11 @@ class DecoderLayer(torch.nn.Module):
 
 class Model(torch.nn.Module):
 
-    def __init__(self, cfg, n_layers, max_bs, max_len, device, seed=0):
+    def __init__(self, cfg, n_layers, max_bs, max_len, device, seed=0, keep_stock=True):
         super().__init__()
-        method = AWQConfig(4, 128, True).get_linear_method()
+        from vllm_quick_amd.layers.quantization.awq import AWQLinearMethod
+        method = AWQLinearMethod(AWQConfig(4, 128, True), keep_stock=keep_stock)
+        self.method = method
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
         self.layers = torch.nn.ModuleList()
@@ -181,6 +183,24 @@ class Model(torch.nn.Module):
             x = layer.linears_only(x)
         return x
 
+    def linears(self):
+        for layer in self.layers:
+            yield from (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj)
+
+    def drop_stock(self):
+        """Releases every layer's stock AWQ tensors (after one call has re-ordered them); bytes released."""
+        return sum(self.method.drop_stock(lin.linear_weights) for lin in self.linears())
+
+    def quantised_weight_bytes(self):
+        """Resident bytes of the quantised linear layers: stock tensors plus private-layout copies."""
+        total = 0
+        for lin in self.linears():
+            total += sum(t.numel() * t.element_size() for n, t in lin.linear_weights.items() if isinstance(t, torch.Tensor))
+            state = lin.linear_weights.get("w4a16_packed")
+            if state is not None:
+                total += state[1].packed_w.numel() + state[1].packed_sz.numel()
+        return total
+
 
 def time_graph(fn, stream, reps=20):
     with torch.cuda.stream(stream):
@@ -207,17 +227,20 @@ def time_graph(fn, stream, reps=20):
 
 
 def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None,
-        fuse_act=True, fuse_add=True):
+        fuse_act=True, fuse_add=True, keep_stock=True):
     cfg = SHAPES[model_name]
     device = device or torch.device("cuda", torch.cuda.current_device())
     n_layers = n_layers or cfg["layers"]
     with torch.inference_mode():
-        model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device)
+        model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device, keep_stock=keep_stock)
         for layer in model.layers:
             layer.fuse_act = fuse_act
             layer.fuse_add = fuse_add
         stream = torch.cuda.Stream(device=device)
         res = {}
+        model.linears_only((torch.randn(1, cfg["hidden"], device=device) * 0.25).half())  # re-orders every layer
+        bytes_both = model.quantised_weight_bytes()
+        released = model.drop_stock()
         for bs in batch_sizes:
             tokens = torch.randint(0, cfg["vocab"], (bs, ), device=device)
             ms = time_graph(lambda: model.step(tokens, ctx_len, ctx_len + 1), stream)
@@ -234,6 +257,8 @@ def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ct
             "layers_model": cfg["layers"], "context": ctx_len, "tp": ps.get_tensor_model_parallel_world_size(),
             "gate_up_activation": "fused into the GEMM epilogue" if fuse_act else "separate elementwise ops",
             "residual_add": "fused into the o_proj / down_proj GEMM epilogue (one rank)" if fuse_add else "separate op",
+            "quantised_weight_bytes_resident": int((bytes_both - released) * cfg["layers"] / n_layers),
+            "stock_tensors": "kept beside the private layout" if keep_stock else "released after re-ordering",
             "by_batch": res}
 
 
@@ -246,6 +271,7 @@ def main():
     ap.add_argument("--no-fuse-act", action="store_true", help="run gate_up GEMM and silu-and-mul as separate ops")
     ap.add_argument("--no-fuse-add", action="store_true", help="add the o_proj / down_proj outputs to the residual "
                     "stream as separate ops")
+    ap.add_argument("--drop-stock", action="store_true", help="release the stock AWQ tensors once re-ordered")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL), or gloo for a "
                     "rehearsal (then every all-reduce must take the peer-to-peer path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -282,7 +308,7 @@ def main():
     from vllm_quick_amd.parallel_utils import rccl_utils as direct
     with (ps.with_rccl_for_all_reduce() if direct.is_initialized() else contextlib.nullcontext()):
         out = run(a.model, tuple(int(v) for v in a.bs.split(",")), a.layers or None, a.ctx,
-                  fuse_act=not a.no_fuse_act, fuse_add=not a.no_fuse_add)
+                  fuse_act=not a.no_fuse_act, fuse_add=not a.no_fuse_add, keep_stock=not a.drop_stock)
     out["wall_s"] = time.time() - t0
     out["all_reduce"] = "peer-to-peer kernel" if world > 1 and a.p2p_all_reduce else ("rccl" if world > 1 else None)
     if world > 1 and a.p2p_all_reduce:

@@ -139,8 +139,11 @@ int w4a16_gemm_packed_f16_tiled_cfg(const void* x, const void* packed_w, const v
  * tests (w4a16_gemm_packed_f16 picks it by itself when it is the faster one): a workgroup owns
  * mt x t tiles of 32 rows x 32 columns; its kw wavefronts split K and each stages the activations of
  * its own K blocks in a private piece of LDS (no barrier in the main loop).  Built combinations only;
- * others return W4A16_E_SHAPE.  In the `_cfg` / `_ex` entry points below this kernel is selected by
- * (mt, t, a = 1, b = -kw).
+ * others return W4A16_E_SHAPE.  kw < 0 selects the variant for many rows instead: a workgroup of nw = -kw
+ * wavefronts owns mt x (t * nw) such tiles over the whole of K, each wavefront t column tiles, all sharing
+ * one activation slab per 128-k block (a ring of three in LDS, one barrier per block, no reduction).
+ * In the `_cfg` / `_ex` entry points below these kernels are selected by (mt, t, a = 1, b = -kw) and
+ * (mt, t, a = nw, b = -1).
  */
 int w4a16_gemm_packed_f16_wide_cfg(const void* x, const void* packed_w, const void* packed_sz,
                                    const void* bias, void* out, int M, int K, int N, int G, int mt,

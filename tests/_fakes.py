@@ -5,6 +5,18 @@ import torch
 from oracle import awq_oracle as orc
 
 
+class FakePacked(tuple):
+    """Stands in for ops.PackedAWQ: an independent copy of the stock tensors."""
+
+    @property
+    def N(self):
+        return self[0].shape[1] * 8
+
+    @property
+    def K(self):
+        return self[0].shape[0]
+
+
 class FakeOps:
 
     def __init__(self):
@@ -19,7 +31,12 @@ class FakeOps:
 
     def awq_repack(self, qweight, scales, qzeros):
         self.trace.append(["repack"])
-        return (qweight, scales, qzeros)
+        return FakePacked((qweight.detach().clone(), scales.detach().clone(), qzeros.detach().clone()))
+
+    def awq_dequantize_packed(self, packed):
+        self.trace.append(["awq_dequantize_packed"])
+        qw, s, qz = packed
+        return torch.from_numpy(orc.dequantize(qw.numpy(), s.numpy(), qz.numpy()))
 
     def awq_gemm_packed(self, x, packed, bias=None, cfg=None):
         self.trace.append(["awq_gemm", list(x.shape), bool(x.is_contiguous())])

@@ -176,7 +176,10 @@ CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 8), (1, 6, 8), (1, 1, 8), (1,
         (8, 3, 2, 2), (8, 3, 1, 2), (4, 6, 1, 4), (2, 6, 1, 4),
         # 32x32x16 kernel: ("wide", mt, t, kw)
         ("wide", 2, 3, 8), ("wide", 2, 2, 8), ("wide", 2, 1, 8), ("wide", 1, 3, 8), ("wide", 1, 2, 8),
-        ("wide", 2, 3, 4), ("wide", 2, 2, 4), ("wide", 1, 3, 4)]
+        ("wide", 2, 3, 4), ("wide", 2, 2, 4), ("wide", 1, 3, 4),
+        # shared-slab 32x32x16 kernel: ("wide", mt, t, -nw)
+        ("wide", 4, 1, -8), ("wide", 4, 2, -4), ("wide", 4, 1, -4), ("wide", 2, 1, -8), ("wide", 2, 2, -8),
+        ("wide", 2, 2, -4)]
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
@@ -266,7 +269,7 @@ def test_default_launch_shape_branches_parity(abi, cuda, K, N, M):
     assert_parity_slack(y, *reference_arithmetic(x, orc.dequantize(qw, s, qz)), what=f"{K}x{N} M={M}")
 
 
-@pytest.mark.parametrize("cfg", [("wide", 2, 3, 8), ("wide", 1, 3, 8), ("wide", 2, 2, 4)])
+@pytest.mark.parametrize("cfg", [("wide", 2, 3, 8), ("wide", 1, 3, 8), ("wide", 2, 2, 4), ("wide", 4, 1, -8), ("wide", 2, 2, -4)])
 def test_full_size_wide_kernel(abi, cuda, full, cfg):
     """The 32x32x16 kernel at 4096 x 11008: oracle parity at 100 (ragged) rows, and unit rows x = e_k,
     which must return rows of the dequantised weights bit for bit (the whole k <-> lane <-> word mapping
@@ -389,6 +392,32 @@ def test_awq_linear_method_matches_reference_fixture(cuda):
             want = arrays[f"apply/{label}/out"].astype(np.float32)
             assert np.allclose(y.float().cpu().numpy(), want, rtol=RTOL, atol=2 * ATOL), label
     assert "w4a16_packed" in weights  # the private layout is kept beside the stock tensors
+
+
+def test_drop_stock_on_gpu(ops, cuda):
+    """keep_stock=False: after drop_stock() the stock tensors are gone and the layer answers from the private
+    layout alone, bit for bit as before, on the fused route and on the dense large-batch route."""
+    from vllm_quick_amd.layers import linear as LL
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    from vllm_quick_amd.layers.quantization.awq import AWQLinearMethod
+    K, N = 512, 384
+    _, qw, s, qz = orc.make_inputs(1, K, N, 128, seed=70)
+    x = dev_t(orc.make_inputs(300, K, N, 128, seed=71)[0], cuda)
+    for threshold in (None, 256):
+        method = AWQLinearMethod(AWQConfig(4, 128, True), fp16_matmul_threshold=threshold, keep_stock=False)
+        layer = LL.ColumnParallelLinear(K, N, bias=False, params_dtype=torch.float16, linear_method=method).to(cuda)
+        for name, arr in (("qweight", qw), ("scales", s), ("qzeros", qz)):
+            p = getattr(layer, name)
+            p.weight_loader(p, torch.from_numpy(arr).to(cuda))
+        before = [layer(x[:m])[0] for m in (5, 300)]
+        free0 = torch.cuda.memory_allocated()
+        released = method.drop_stock(layer.linear_weights)
+        assert released == qw.nbytes + s.nbytes + qz.nbytes and layer.qweight.numel() == 0
+        assert torch.cuda.memory_allocated() <= free0 - released + 4096
+        after = [layer(x[:m])[0] for m in (5, 300)]
+        assert all(torch.equal(a, b) for a, b in zip(before, after))
+        fused = method.apply_weights_silu_and_mul(layer.linear_weights, x[:5])
+        assert fused.shape == (5, N // 2)
 
 
 def test_linear_layers_on_gpu(cuda):

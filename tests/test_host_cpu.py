@@ -123,22 +123,47 @@ def test_threshold_none_always_uses_fused_kernel(arrays, monkeypatch):
     assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm"]
 
 
-def test_default_switch_point_is_the_measured_one(arrays, monkeypatch):
-    """By default the fused kernel serves every batch below 1024 tokens (it is the faster route
-    there on MI355X); from 1024 the dequantise + matmul route of awq.py:154-159 takes over."""
+def test_default_is_the_fused_kernel_at_every_batch(arrays, monkeypatch):
+    """By default the fused kernels serve every batch (they are ahead of dequantise + matmul at every token
+    count measured on MI355X); the reference's route at its 256-token switch point (awq.py:154-159) is one
+    argument away."""
     fake = FakeOps()
     monkeypatch.setattr(awq_mod, "ops", fake)
     method = AWQConfig(4, 128, True).get_linear_method()
-    assert method.fp16_matmul_threshold == 1024
+    assert method.fp16_matmul_threshold is None and method.keep_stock
     weights = {k: torch.from_numpy(arrays[f"apply/{k}"]) for k in ("qweight", "scales", "qzeros")}
     x = torch.from_numpy(arrays["apply/m256/x"])
-    method.apply_weights(weights, x)
     big = x.repeat(4, 1)
-    assert big.shape[0] == 1024
     y = method.apply_weights(weights, big)
-    assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm", "awq_dequantize"]
+    assert [t[0] for t in fake.trace if t[0] != "repack"] == ["awq_gemm"]
     want = arrays["apply/m256/out"].astype(np.float32)
     assert np.allclose(y[:256].numpy().astype(np.float32), want, rtol=1e-2, atol=1e-3)
+    ref = awq_mod.AWQLinearMethod(AWQConfig(4, 128, True), fp16_matmul_threshold=256)
+    ref.apply_weights(weights, x)
+    assert fake.trace[-1][0] == "awq_dequantize"
+
+
+def test_drop_stock_releases_the_stock_tensors(arrays, monkeypatch):
+    """`keep_stock=False`: after drop_stock() the layer answers from the private layout alone, on the fused
+    route and on the dense large-batch route (dequantised from the private layout, bit-identical)."""
+    fake = FakeOps()
+    monkeypatch.setattr(awq_mod, "ops", fake)
+    weights = {k: torch.from_numpy(arrays[f"apply/{k}"]).clone() for k in ("qweight", "scales", "qzeros")}
+    x = torch.from_numpy(arrays["apply/m256/x"])
+    keep = AWQConfig(4, 128, True).get_linear_method()
+    want = keep.apply_weights(dict(weights), x)
+    assert keep.drop_stock(weights) == 0 and weights["qweight"].numel() > 0  # keep_stock: nothing released
+    method = awq_mod.AWQLinearMethod(AWQConfig(4, 128, True), keep_stock=False)
+    nbytes = sum(t.numel() * t.element_size() for t in weights.values())
+    assert method.drop_stock(weights) == nbytes
+    assert all(weights[k].numel() == 0 for k in ("qweight", "scales", "qzeros"))
+    assert method.drop_stock(weights) == 0  # idempotent
+    y = method.apply_weights(weights, x.view(2, 128, -1))
+    assert y.shape == (2, 128, want.shape[-1]) and torch.equal(y.view(256, -1), want)
+    dense = awq_mod.AWQLinearMethod(AWQConfig(4, 128, True), fp16_matmul_threshold=256, keep_stock=False)
+    yd = dense.apply_weights(weights, x)
+    assert fake.trace[-1][0] == "awq_dequantize_packed"
+    assert np.allclose(yd.numpy().astype(np.float32), want.numpy().astype(np.float32), rtol=1e-2, atol=1e-3)
 
 
 # --------------------------------------------------------------------------

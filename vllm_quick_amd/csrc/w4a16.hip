@@ -51,6 +51,12 @@
 #ifndef W4A16_HEAD
 #define W4A16_HEAD 1
 #endif
+#ifndef W4A16_TMAJOR
+#define W4A16_TMAJOR 1  // streaming kernel: tile-major arithmetic order within a block
+#endif
+#ifndef W4A16_SLIM
+#define W4A16_SLIM 1    // streaming kernel: compact cross-wave reduction for up to 4 rows
+#endif
 #ifndef W4A16_ILV
 #define W4A16_ILV 1  // the 32x32x16 kernel deals matrix and conversion instructions out alternately
 #endif
@@ -318,6 +324,24 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   // Without XPRE, `xf` holds the x fragments of this block's first k-step on entry and those of
   // block `kb_next`'s first k-step on exit (loaded one k-step ahead throughout).
   auto compute_block = [&](int kb, int kb_next, const Block& b, f16x8 (&xf)[MT]) {
+    if constexpr (XPRE && W4A16_TMAJOR) {
+      // Tile by tile, in the order the weight loads were issued: the wave starts on its first tile while
+      // the others are still on their way (a wave's loads complete in issue order, so the compiler's wait
+      // before tile t lets the loads of tiles t + 1.. stay outstanding).
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        SZ ct;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j % SZS == 0) ct = expand_sz(b.sz[t][j / SZS]);
+          const f16x8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(f16x8, b.q[t]) : dequant_word(b.q[t][j], ct, dqc);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b.x[j][mt], acc[t][mt], 0, 0, 0);
+        }
+      }
+      return;
+    }
     SZ c[T];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -439,6 +463,43 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
     }
   };
   constexpr int OUTS = H * MT;  // stores per workgroup: tiles, or gate/up tile pairs
+  if (W > 1 && MT == 1 && W4A16_SLIM && a.M <= 4) {
+    // Up to 4 rows: of a wave's 16 x 16 partial tile only the lanes of tokens 0..M-1 (l & 15 < M) hold
+    // anything that is stored.  They park their 16 bytes compactly, [wave][tile][token][l >> 4], 256 bytes
+    // per wave and tile instead of 1 KiB, and the first wave alone sums the W partials of every
+    // (tile, token, 4-column group): W independent 16-byte reads per lane, one round trip.
+    if (n16 < 4) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) red[((w * T + t) * 4 + n16) * 4 + kq] = acc[t][0];
+    }
+    __syncthreads();
+    if (w != 0) return;
+    const int item = lane;  // (tile or tile pair, token, column group)
+    const int ti = item / 16, tok = (item >> 2) & 3, grp = item & 3;
+    if (ti >= OUTS || tok >= a.M) return;
+    f32x4 v = red[(ti * 4 + tok) * 4 + grp];
+#pragma unroll
+    for (int s = 1; s < W; ++s) v += red[((s * T + ti) * 4 + tok) * 4 + grp];
+    f32x4 vu = v;
+    if constexpr (ACT) {
+      vu = red[((ti + H) * 4 + tok) * 4 + grp];
+#pragma unroll
+      for (int s = 1; s < W; ++s) vu += red[((s * T + ti + H) * 4 + tok) * 4 + grp];
+    }
+    const int nt = nt0 + ti, n = nt * 16 + grp * 4, m = m0 + tok;
+    if constexpr (ACT) {
+      const int NH = a.N / 2;
+      if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+    } else {
+      if (nt < a.NT && n < a.N) {
+        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+        f16x4 hv = finish(v, n);
+        if (a.add_out) hv = *dst + hv;
+        *dst = hv;
+      }
+    }
+    return;
+  }
   if constexpr (W == 1) {
 #pragma unroll
     for (int i = 0; i < OUTS; ++i)
@@ -1097,6 +1158,211 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 }
 
 // ---------------------------------------------------------------------------
+// 32x32x16 GEMM for many rows: one activation slab shared by all waves of the workgroup
+// ---------------------------------------------------------------------------
+// With hundreds of rows and more the workgroup's traffic, not its arithmetic, decides: a [32 MT] x [32 T NW]
+// tile re-reads its activation rows once per workgroup, so the wider the tile the fewer bytes per
+// matrix instruction.  Here the NW waves of a workgroup each own T 32-column tiles for all MT 32-row
+// tiles over the WHOLE of K (no K split, so no cross-wave reduction: results go from the accumulators
+// straight to memory), and share the [32 MT rows] x [128 k] activation slab of the current block, which
+// the waves fetch together by LDS-DMA into a ring of three slabs (256-byte rows, 16-byte chunks
+// XOR-swizzled by the row), two blocks ahead.  A weight fragment converted once feeds MT matrix
+// instructions: with MT = 4 the conversion takes a quarter of the vector issue slots of the 16x16x32
+// kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
+// landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
+template <int MT, int T, int NW, int SZS>
+__global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
+                                                                   const GemmArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+  fetch_args_now(ga);
+  asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
+  const GemmArgs a = batch_slice(ga);
+  constexpr int R = MT * 32;
+  constexpr int SLAB = R * 256;             // bytes: R rows x 128 k
+  constexpr int PIECES = R / 4;             // DMA instructions per slab (4 rows x 256 bytes each)
+  static_assert(PIECES % NW == 0, "every wave fetches the same number of pieces");
+  constexpr int ND = PIECES / NW;           // ... per wave
+  constexpr int NSZ = 4 / SZS;
+  constexpr int WL = T * (NSZ + 2);         // register loads per weight block and wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
+  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
+  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
+  const int slice = (in_panel / rows_here) * 8 + xcd;
+  const int mb = panel * panel_rows + in_panel % rows_here;
+  if (slice >= n_slices) return;  // whole workgroup
+  const int ct0 = (slice * NW + w) * T;  // this wave's first 32-column tile
+  const int m0 = mb * R;
+
+  uint32_t woff[T], szoff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int t16 = min(2 * (ct0 + t) + ((lane >> 4) & 1), a.NT - 1);
+    woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
+    szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
+  }
+  // this wave's pieces of a slab: piece p = w + NW j covers rows 4 p .. 4 p + 3; lane -> row 4 p + (lane >> 4),
+  // 16-byte position lane & 15, which holds chunk (lane & 15) ^ (row & 15) of the row's 128 k
+  uint32_t xoff[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int row = 4 * (w + NW * j) + (lane >> 4);
+    xoff[j] = ((uint32_t)min(m0 + row, a.M - 1) * a.K + ((lane & 15) ^ (row & 15)) * 8) * 2u;
+  }
+  // B fragment of k-step ks (0..7): row r32 (+ 32 mt), chunk 2 ks + h
+  const int xrd = r32 * 256;
+  const int xsw = r32 & 15;
+
+  f32x16 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  const DqConst dqc = make_dq_const();
+
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  struct WSet {
+    uint32_t sz[T][NSZ];
+    u32x4 q[T][2];
+  };
+  auto load_w = [&](int kb, WSet& b) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
+      b.q[t][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + 512, kb * 1024, 0);
+    }
+  };
+  auto dma_x = [&](int kb, int buf) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w + NW * j) * 1024), 16, xoff[j],
+          kb * 256, 0, 0);
+  };
+  auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
+  };
+  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+  };
+  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
+    f16x8 af[T + 1];
+    af[0] = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T)
+        af[t + 1] = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        af[T] = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+    }
+    if (kstep + 1 < 8) af0 = af[T];
+    constexpr int per = (13 + MT - 1) / MT;
+#pragma unroll
+    for (int i = 0; i < T * MT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+    }
+  };
+  // Block i from weight set `cur` in ring slab i % 3.  A wave's vector-memory operations, in issue order:
+  //   D(0), D(1), W(0) | D(2), W(1) | D(3), W(2) | ..      (D = its ND DMA loads of a slab, W = WL loads)
+  // one group per block, issued right after the block's barrier.  Before the barrier of block i the wave's
+  // own share of D(i) must have landed: all but the ND + WL youngest (D(i+1), W(i)) are done then; in the
+  // last block D(i+1) does not exist: all but the WL youngest.
+  // DMA 0/1: whether D(i+2) exists; LW: whether W(i+1) exists.
+  auto block = [&](auto dma, auto lw, int i, const WSet& cur, WSet& nxt) {
+    constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
+    const int base = (i % 3) * SLAB + xrd;
+    wait_vmcnt<LW ? ND + WL : WL>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DMA) dma_x(i + 2, (i + 2) % 3);
+    if constexpr (LW) load_w(i + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    SZ c[T];
+    f16x8 xa[MT], xb[MT];
+    read_x(0, base, xa);
+    f16x8 af0 = convert(0, 0, cur, c);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      read_x(k2 + 1, base, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2, cur, c, xa, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 + 2 < 8) read_x(k2 + 2, base, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2 + 1, cur, c, xb, af0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int n = a.KB;  // >= 2 (host-checked)
+  WSet w0, w1;
+  dma_x(0, 0);
+  dma_x(1, 1);
+  load_w(0, w0);
+  __builtin_amdgcn_sched_barrier(0);
+  int i = 0;
+  for (; i + 2 <= n - 2; i += 2) {
+    block(Flag<true>{}, Flag<true>{}, i, w0, w1);
+    block(Flag<true>{}, Flag<true>{}, i + 1, w1, w0);
+  }
+  if (i < n - 2) {
+    block(Flag<true>{}, Flag<true>{}, i, w0, w1);
+    w0 = w1;
+    ++i;
+  }
+  block(Flag<false>{}, Flag<true>{}, i, w0, w1);
+  block(Flag<false>{}, Flag<false>{}, i + 1, w1, w0);
+
+  // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = (ct0 + t) * 32 + 8 * q + 4 * h;
+        const int m = m0 + mt * 32 + r32;
+        if (m < a.M && nn < a.N) {
+          f16x4 hv = f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2],
+                           (f16)acc[t][mt][4 * q + 3]};
+          if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + nn);
+          f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + nn);
+          if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+          *dst = hv;
+        }
+      }
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // Shape-agnostic GEMM on the stock layout (no repack, no workspace)
 // ---------------------------------------------------------------------------
 // One thread owns one packed column word (8 output columns) for up to RB rows.
@@ -1508,6 +1774,47 @@ int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int b
   return W4A16_E_SHAPE;
 }
 
+template <int MT, int T, int NW>
+int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch) {
+  constexpr int lds = 3 * MT * 32 * 256;  // ring of three slabs
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  // whole 128-k blocks, at least two of them, and 32-bit byte offsets into the three buffers
+  if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
+    return W4A16_E_SHAPE;
+  const int n_slices = ceil_div(ceil_div(a.N, 32), T * NW);
+  const int m_blocks = ceil_div(a.M, MT * 32);
+  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  void (*kern)(int, int, int, const GemmArgs) = nullptr;
+  if (a.G % 128 == 0)
+    kern = gemm_wide_shared_kernel<MT, T, NW, 4>;
+  else if (a.G == 64)
+    kern = gemm_wide_shared_kernel<MT, T, NW, 2>;
+  else
+    kern = gemm_wide_shared_kernel<MT, T, NW, 1>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+  }
+  const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW), lds, s, n_slices, m_blocks, panel_rows, a);
+  return launched();
+}
+
+// (mt, t, nw) of the shared-slab 32x32x16 kernel
+#define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(4, 2, 4) X(4, 1, 4) X(2, 1, 8) X(2, 2, 8) X(2, 2, 4) X(2, 3, 8)
+
+int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1) {
+#define X(MT_, T_, NW_) \
+  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch);
+  W4A16_FOR_EACH_WIDE_SHARED(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
 // (mt, t, waves) -> instantiation.  mt in {1,2,4,8}; t in 1..8 with mt*t <= 24;
 // waves 16 for mt <= 2 (128 VGPRs/lane are enough), 8 for mt >= 4; plus 4/8 for short K.
 #define W4A16_FOR_EACH_CFG(X) \
@@ -1550,8 +1857,67 @@ struct Choice {
   int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
 };
 
+// Launch shape of the 32x32x16 kernel (gemm_wide_kernel) for 33-256 rows: the candidate with the lowest
+// estimated time.  A workgroup's time is the larger of its arithmetic (matrix instructions at 32 cycles
+// each over 4 SIMDs; the int4 -> fp16 conversion, 13 vector instructions per weight word, overlaps them
+// when a SIMD has two waves to alternate between and adds to them when it has one) and of the bytes it pulls
+// through the CU's vector memory path, plus a fixed cost for prologue, cross-wave reduction and stores;
+// the busiest CU runs ceil(workgroups / 256) of them.  The five constants were fitted on all built shapes
+// x 11 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral) x 48-256 rows
+// (scripts/exp_wide.py): mean loss against the best built shape 0.4 %, worst 6 %.
+Choice choose_wide(int M, int K, int N, int batch) {
+  static const int cand[][3] = {{2, 3, 8}, {2, 2, 8}, {2, 1, 8}, {1, 3, 8}, {1, 2, 8}, {2, 3, 4}, {2, 2, 4}, {1, 3, 4}};
+  const double KB = K / 128;
+  Choice best{true, 2, 3, 1, -8};
+  double best_cost = 1e300;
+  for (const auto& c : cand) {
+    const int mt = c[0], t = c[1], kw = c[2];
+    const int slab = kw * mt * 8192, red = (kw > 4 ? kw / 2 : kw) * t * mt * 4096;
+    const int resident = 160 * 1024 / (slab > red ? slab : red);  // workgroups a CU holds at once (LDS)
+    const long long wgs = (long long)ceil_div(ceil_div(N, 32), t) * ceil_div(M, 32 * mt) * batch;
+    const double load = (double)((wgs + 255) / 256);
+    const double mfma = KB * 8 * t * mt * 32 / 4, conv = KB * 8 * t * 13 * 4 / 4, issue = KB * 8 * t * mt * 8 / 4;
+    const double comp = (kw == 8 || resident > 1) ? (mfma > 1.2 * (conv + issue) ? mfma : 1.2 * (conv + issue))
+                                                  : mfma + 0.6 * conv;
+    const double mem = (32.0 * mt * K * 2 + 32.0 * t * K / 2) / 48;
+    const double body = comp > mem ? comp : mem;
+    const double fixed = 9000 * (kw == 8 ? 1.3 : 1.0);
+    const double cost = resident > 1 ? load * body + fixed * (double)(((long long)load + resident - 1) / resident)
+                                     : load * (body + fixed);
+    if (cost < best_cost) best_cost = cost, best = Choice{true, mt, t, 1, -kw};
+  }
+  return best;
+}
+
+// Launch shape of the shared-slab 32x32x16 kernel (gemm_wide_shared_kernel) above 256 rows: whole rounds
+// of 256 workgroups times a workgroup's time, which is its tile area over the rate a busy CU sustains
+// with that shape (measured at 4096 rows on 4096 x 11008, relative to the 128 x 256 tile) plus a fixed
+// prologue / epilogue share (about an eighth of a 128 x 256 workgroup's time at K = 4096).
+Choice choose_wide_shared(int M, int K, int N, int batch) {
+  static const int cand[][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}, {2, 3}};
+  static const double rate[] = {1.0, 1.048, 0.854, 0.905, 0.914};
+  Choice best{true, 4, 1, 1, -8};
+  double best_cost = 1e300;
+  for (int i = 0; i < 5; ++i) {
+    const int mt = cand[i][0], t = cand[i][1];
+    const long long wgs = (long long)ceil_div(ceil_div(N, 32), t * 8) * ceil_div(M, 32 * mt) * batch;
+    const double cost = (double)((wgs + 255) / 256) * (mt * t / rate[i] + 0.5 * 4096.0 / K);
+    if (cost < best_cost) best_cost = cost, best = Choice{true, mt, t, 8, -1};  // a = nw, b = -1: the shared-slab kernel
+  }
+  return best;
+}
+
 Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
+  // 33-256 rows: the 32x32x16 kernel, 10-40 % faster than the 16x16x32 kernels on every layer shape measured
+  // (whole 128-k blocks and 32-bit byte offsets only; no fused activation)
+  if (!act && M > 32 && M <= 256 && K % 128 == 0 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
+      (long long)M * K < (1LL << 31))
+    return choose_wide(M, K, N, batch);
+  // more rows: one activation slab shared by the workgroup's eight waves, wide tiles
+  if (!act && M > 256 && K % 128 == 0 && K >= 256 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
+      (long long)M * K < (1LL << 31))
+    return choose_wide_shared(M, K, N, batch);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
   // 24-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
@@ -1799,6 +2165,7 @@ int w4a16_gemm_packed_f16_wide_cfg(const void* x, const void* packed_w, const vo
   const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
   if (rc) return rc;
   clear_stale_error();
+  if (kw < 0) return dispatch_wide_shared(a, mt, t, -kw, static_cast<hipStream_t>(stream));
   return dispatch_wide(a, mt, t, kw, static_cast<hipStream_t>(stream));
 }
 
@@ -1806,6 +2173,9 @@ int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packe
                           const void* bias, void* out, int M, int K, int N, int G, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0) return W4A16_E_SHAPE;
   const Choice c = choose_cfg(M, K, N);
+  if (c.tiled && c.b < 0)  // 32x32x16 kernels: (mt, t, 1, -kw) private slabs, (mt, t, nw, -1) shared slab
+    return w4a16_gemm_packed_f16_wide_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t,
+                                          c.a > 1 ? -c.a : -c.b, stream);
   if (c.tiled)
     return w4a16_gemm_packed_f16_tiled_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t,
                                            c.a, c.b, stream);
@@ -1846,7 +2216,10 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
     const Choice c = choose_cfg(M, K, N, busy, act);
     mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
   }
-  if (b_ < 0) return act ? W4A16_E_SHAPE : dispatch_wide(a, mt, t, -b_, s, batch);
+  if (b_ < 0) {  // 32x32x16 kernels: (mt, t, 1, -kw) private slabs, (mt, t, nw > 1, any b < 0) shared slab
+    if (act) return W4A16_E_SHAPE;
+    return a_ > 1 ? dispatch_wide_shared(a, mt, t, a_, s, batch) : dispatch_wide(a, mt, t, -b_, s, batch);
+  }
   if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
   return dispatch_packed(a, mt, t, a_, s, batch, act);
 }

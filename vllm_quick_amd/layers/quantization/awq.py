@@ -22,6 +22,7 @@ from ..linear import LinearMethodBase, set_weight_attrs
 from .base_config import QuantizationConfig
 
 _PACKED_KEY = "w4a16_packed"
+_DROPPED_KEY = "w4a16_stock_dropped"
 
 
 class AWQConfig(QuantizationConfig):
@@ -77,19 +78,23 @@ class AWQLinearMethod(LinearMethodBase):
         fp16_matmul_threshold: token count from which `apply_weights` dequantises the
             weights to HBM and calls `torch.matmul`, the reference's large-batch route
             (awq.py:154-159).  The reference switches at 256 tokens, a heuristic tuned to its
-            CUDA kernel; on MI355X the fused kernel stays ahead of dequantise + hipBLASLt up to
-            about a thousand tokens on Llama-2 shapes (2.2x at 256, 1.4x at 512, level between
-            1024 and 2048, behind at 4096), so the default here is 1024.  Pass 256 for the reference's exact
-            operator choice, `None` to always use the fused kernel.
+            CUDA kernel; on MI355X the fused kernels stay ahead of dequantise + hipBLASLt at every
+            token count measured (2.5x at 256 tokens, 1.2x at 1024, 1.1x at 4096 on 4096 x 11008), so
+            the default here is `None`: always the fused kernels.  Pass 256 for the reference's exact
+            operator choice.
+        keep_stock: `False` lets `drop_stock()` release a layer's stock tensors once they have been
+            re-ordered into the private layout (the reference's GPTQ path re-orders its weights in place
+            on first use in the same spirit, gptq.py:197-204); otherwise both copies stay resident.
     """
 
     REFERENCE_FP16_MATMUL_THRESHOLD = 256
-    DEFAULT_FP16_MATMUL_THRESHOLD = 1024
+    DEFAULT_FP16_MATMUL_THRESHOLD = None
 
     def __init__(self, quant_config: AWQConfig,
-                 fp16_matmul_threshold: Optional[int] = DEFAULT_FP16_MATMUL_THRESHOLD):
+                 fp16_matmul_threshold: Optional[int] = DEFAULT_FP16_MATMUL_THRESHOLD, keep_stock: bool = True):
         self.quant_config = quant_config
         self.fp16_matmul_threshold = fp16_matmul_threshold
+        self.keep_stock = keep_stock
 
     def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
                        output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
@@ -115,9 +120,30 @@ class AWQLinearMethod(LinearMethodBase):
         set_weight_attrs(scales, {"input_dim": 0, "output_dim": 1})
         return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
 
+    def drop_stock(self, weights: Dict[str, Any]) -> int:
+        """Re-orders the layer's weights into the private layout (if that has not happened yet) and
+        releases the stock `qweight` / `qzeros` / `scales` storages: from then on the layer holds its
+        4-bit weights once instead of twice.  Call after weight loading, outside graph capture.  The
+        parameters stay registered (empty) so that module traversal keeps working; loading new weights
+        into them afterwards is not supported.  Returns the bytes released (0 if `keep_stock`)."""
+        if self.keep_stock or weights.get(_DROPPED_KEY):
+            return 0
+        packed = self._packed(weights)
+        if packed is None:
+            raise RuntimeError("drop_stock() cannot re-order weights during graph capture")
+        freed = 0
+        for name in ("qweight", "qzeros", "scales"):
+            t = weights[name]
+            freed += t.numel() * t.element_size()
+            t.data = torch.empty(0, dtype=t.dtype, device=t.device)
+        weights[_DROPPED_KEY] = True
+        return freed
+
     @staticmethod
     def _packed(weights: Dict[str, Any]) -> Optional[ops.PackedAWQ]:
         """The layer's MFMA-ordered weights, (re)built when the stock tensors changed."""
+        if weights.get(_DROPPED_KEY):
+            return weights[_PACKED_KEY][1]
         stock = (weights["qweight"], weights["scales"], weights["qzeros"])
         stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for t in stock)
         state = weights.get(_PACKED_KEY)
@@ -132,13 +158,16 @@ class AWQLinearMethod(LinearMethodBase):
     def apply_weights(self, weights: Dict[str, Any], x: torch.Tensor,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         qweight, scales, qzeros = weights["qweight"], weights["scales"], weights["qzeros"]
-        pack_factor = self.quant_config.pack_factor
-        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor, )
+        dropped = bool(weights.get(_DROPPED_KEY))
+        n_out = weights[_PACKED_KEY][1].N if dropped else qweight.shape[-1] * self.quant_config.pack_factor
+        out_shape = x.shape[:-1] + (n_out, )
         reshaped_x = x.reshape(-1, x.shape[-1])
         num_tokens = x.shape[:-1].numel()
 
         if self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold:
-            dense = ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
+            # (bit-identical dense weights from either layout)
+            dense = ops.awq_dequantize_packed(weights[_PACKED_KEY][1]) if dropped else \
+                ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
             out = torch.matmul(reshaped_x, dense)
             if bias is not None:
                 out = out + bias
@@ -158,8 +187,8 @@ class AWQLinearMethod(LinearMethodBase):
         """silu(y[..., :N/2]) * y[..., N/2:] for y = apply_weights(weights, x, bias): the merged gate_up
         projection of a gated MLP followed by `SiluAndMul` (llama.py:74-80), with the activation fused
         into the GEMM epilogue where the fused kernel serves the call."""
-        qweight = weights["qweight"]
-        n_out = qweight.shape[-1] * self.quant_config.pack_factor
+        n_out = weights[_PACKED_KEY][1].N if weights.get(_DROPPED_KEY) else \
+            weights["qweight"].shape[-1] * self.quant_config.pack_factor
         num_tokens = x.shape[:-1].numel()
         large = self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold
         packed = None if (large or n_out % 32) else self._packed(weights)
