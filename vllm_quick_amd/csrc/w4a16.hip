@@ -855,9 +855,9 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
 // half's k-steps to arrive.  No other wave touches that LDS, so the main loop has no barrier; the
 // DMA's completion is awaited with counted s_waitcnt vmcnt (vector-memory operations of a wave complete
 // in issue order; the compiler does not track data that arrives in LDS this way).
-template <bool V>
+template <int V>
 struct Flag {
-  static constexpr bool value = V;
+  static constexpr int value = V;
 };
 
 template <int N>
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   const GemmArgs a = batch_slice(ga);
   constexpr int R = MT * 32;             // rows of the workgroup's tile
   constexpr int HALF = R * 128;          // bytes of a half slab: R rows x 64 k
-  constexpr int SLAB = 2 * HALF;
+  constexpr int SLAB = 2 * HALF;         // LDS per wave
   constexpr int XLR = R / 8;             // DMA loads per half slab (8 rows x 128 bytes each)
   constexpr int XL = (W4A16_DBG & 1) ? 1 : XLR;
   constexpr int NSZ = 4 / SZS;           // scale/zero words per 128-k block and tile
@@ -971,6 +971,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
     }
   };
   // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
+  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
   auto dma_x = [&](int kb, int hp) {
 #pragma unroll
     for (int p = 0; p < XL; ++p)  // (ablation 1: XL is 1, an eighth of the activation traffic)
@@ -1019,24 +1020,26 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       }
     }
   };
-  // One 128-k block from weight set `cur`.  With PF the wave's next block is requested meanwhile: its
-  // weights into `nxt` at the start, each half of its slab into the LDS half just consumed.  A wave's
-  // vector-memory operations, in issue order, are thus
+  // One 128-k block from weight set `cur`.  Unless it is the wave's last (LAST), the next block (kb_next)
+  // is requested meanwhile: its weights into `nxt` at the start, each half of its slab into the LDS half
+  // just consumed.  A wave's vector-memory operations, in issue order, are thus
   //   W(0), D0(0), D1(0), W(1), D0(1), D1(1), W(2), ..          (D = XL DMA loads, W = WL loads)
   // Half 0 of block i is read from the start of the block: all but the XL + WL youngest must be done
   // (XL in the last block, which requests nothing).  Half 1 is first read during k-step 3 (fragments
   // are fetched one k-step ahead), before D0(i+1) is issued: all but the WL youngest (none in the last
   // block).  A half is overwritten only after the matrix instructions of its last k-step were issued,
-  // i.e. after its last read returned.
-  auto block = [&](auto pf, int kb_next, const WSet& cur, WSet& nxt) {
-    constexpr bool PF = decltype(pf)::value;
+  // i.e. after its last read returned.  (Three half slabs per wave, the DMA a whole block ahead, were
+  // tried where LDS allows: no faster at 4 waves, and slower wherever the extra LDS costs a resident
+  // workgroup.)
+  auto block = [&](auto last_, int kb_next, const WSet& cur, WSet& nxt) {
+    constexpr bool LAST = decltype(last_)::value != 0;
     SZ c[T];
     f16x8 xa[MT], xb[MT];
-    if constexpr (PF) {
+    if constexpr (!LAST) {
       load_w(kb_next, nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
-    wait_vmcnt<PF ? XL + WL : XL>();
+    wait_vmcnt<LAST ? XL : XL + WL>();
     read_x(0, xa);
     f16x8 af0 = convert(0, 0, cur, c);
 #pragma unroll
@@ -1046,12 +1049,12 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       __builtin_amdgcn_sched_barrier(0);
       math(k2, cur, c, xa, af0);
       __builtin_amdgcn_sched_barrier(0);
-      if (k2 + 1 == 3) wait_vmcnt<PF ? WL : 0>();
+      if (k2 + 1 == 3) wait_vmcnt<LAST ? 0 : WL>();
       if (k2 + 2 < 8) read_x(k2 + 2, xa);
       __builtin_amdgcn_sched_barrier(0);
       math(k2 + 1, cur, c, xb, af0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PF) {
+      if constexpr (!LAST) {
         if (k2 + 1 == 3) dma_x(kb_next, 0);
         if (k2 + 1 == 7) dma_x(kb_next, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1088,16 +1091,16 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
     int i = 0;
     for (; i + 2 < nblk; i += 2) {
       const int k1 = next(kb), k2 = next(k1);
-      block(Flag<true>{}, k1, w0, w1);
-      block(Flag<true>{}, k2, w1, w0);
+      block(Flag<0>{}, k1, w0, w1);
+      block(Flag<0>{}, k2, w1, w0);
       kb = k2;
     }
     if (i + 1 < nblk) {
       kb = next(kb);
-      block(Flag<true>{}, kb, w0, w1);
+      block(Flag<0>{}, kb, w0, w1);
       w0 = w1;
     }
-    block(Flag<false>{}, kb, w0, w1);
+    block(Flag<1>{}, kb, w0, w1);
   }
 
   // Cross-wave reduction through LDS (the slabs are free once every wave is past this barrier).  A
@@ -1330,16 +1333,16 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   __builtin_amdgcn_sched_barrier(0);
   int i = 0;
   for (; i + 2 <= n - 2; i += 2) {
-    block(Flag<true>{}, Flag<true>{}, i, w0, w1);
-    block(Flag<true>{}, Flag<true>{}, i + 1, w1, w0);
+    block(Flag<1>{}, Flag<1>{}, i, w0, w1);
+    block(Flag<1>{}, Flag<1>{}, i + 1, w1, w0);
   }
   if (i < n - 2) {
-    block(Flag<true>{}, Flag<true>{}, i, w0, w1);
+    block(Flag<1>{}, Flag<1>{}, i, w0, w1);
     w0 = w1;
     ++i;
   }
-  block(Flag<false>{}, Flag<true>{}, i, w0, w1);
-  block(Flag<false>{}, Flag<false>{}, i + 1, w1, w0);
+  block(Flag<0>{}, Flag<1>{}, i, w0, w1);
+  block(Flag<0>{}, Flag<0>{}, i + 1, w1, w0);
 
   // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
 #pragma unroll
