@@ -18,11 +18,13 @@ from HBM on every launch.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       dominant kernel of the timed region (M = 128, MFMA-bound),
   roofline_m1    the M = 1 decode launch of the same layer (HBM-bound), N = 1 only,
-  sweep          per-M kernel times of the whole M sweep, N = 1 only,
+  sweep          per-M kernel times of the whole M sweep (and of the stock-layout kernel, which serves a call
+                 only when no packed copy can be made), N = 1 only,
   cpu_baseline   torch.matmul(x, dequant(W)) with the oracle's dequantiser on the host cores, N = 1 only,
   decode         Llama-2-7B-AWQ-shaped greedy decode tokens/s (benchmarks/llama_decode.py), N = 1 only,
   experts        Mixtral-8x7B-shaped expert block, batched launches vs per-expert loop, N = 1 only,
-  tp             column-/row-parallel halves of the step timed separately.
+  tp             column-/row-parallel halves of the step and the all-reduce timed separately, with the
+                 roofline of each half on this rank's shard.
 """
 from __future__ import annotations
 
@@ -136,12 +138,30 @@ def cpu_baseline(M, K, N, G):
 
 
 def load_traffic():
-    """HBM bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes), if any."""
+    """HBM bytes per launch from the committed PMC profile (separate rocprofv3 --pmc passes), if any.
+    The file names the kernels it measured; figures of a kernel that is no longer the one launched are
+    not reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
     return {}
+
+
+def traffic_of(traffic, key, kernel):
+    """The measured HBM bytes per launch under `key`, if the profile was taken on `kernel`."""
+    if traffic.get(f"{key}_kernel") != kernel:
+        return None
+    return traffic.get(f"{key}_hbm_bytes_per_launch")
+
+
+def shard_roofline(M, K, n, G, us):
+    """MFMA roofline of one launch on a [K, n] shard: algorithmic flops / mean launch duration."""
+    from vllm_quick_amd._lib import launch_shape
+    fl = 2.0 * M * K * n
+    return {"kernel": launch_shape(M, K, n), "bound": "mfma", "achieved": fl / us * 1e-6, "peak": PEAK_F16_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / us * 1e-6 / PEAK_F16_TFLOPS,
+            "algorithmic_bytes": algorithmic_bytes(M, K, n, G), "launch_us": us}
 
 
 def run_children(script, script_args, rank, world, timeout_s=180):
@@ -206,6 +226,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--sweep-ms", default="1,8,16,32,128,512,1024,4096",
+                    help="batch sizes of the sweep (1 must be among them); counter passes use 1,128 so that "
+                         "each kernel's launches are of one size")
     ap.add_argument("--no-decode", action="store_true", help="skip the Llama-2-7B-shaped decode harness and the Mixtral-shaped experts block")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: skip the peer-to-peer all-reduce comparison (child processes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
@@ -368,7 +391,10 @@ def main():
                            launches, args.warmup)
     row_us = time_launches([(lambda i=i: ops.awq_gemm_packed(x_row, row[i])) for i in range(NBUF)], stream,
                            launches, args.warmup)
-    tp = {"column_gemm_us": col_us, "row_gemm_us": row_us}
+    tp = {"column_gemm_us": col_us, "row_gemm_us": row_us, "all_reduce_us": 0.0, "collective": "none (one rank)",
+          "column_shard": [K, N // p], "row_shard": [K // p, N],
+          "column_roofline": shard_roofline(M, K, N // p, G, col_us),
+          "row_roofline": shard_roofline(M, K // p, N, G, row_us)}
     if world > 1:
         with torch.cuda.stream(stream):
             y = ops.awq_gemm_packed(x_row, row[0])
@@ -424,15 +450,17 @@ def main():
     traffic = load_traffic()
     n_local = N // p
     flops_launch = 2.0 * M * K * n_local
+    from vllm_quick_amd._lib import launch_shape
+    kernel = launch_shape(M, K, n_local)
     out["roofline"] = {
-        "kernel": ("gemm_tiled_kernel<4,3,2,4> (the M=128 launch w4a16_gemm_packed_f16 makes)" if p == 1 else
-                   f"the M=128 launch w4a16_gemm_packed_f16 makes on this rank's [{K}, {N // p}] column shard"),
+        "kernel": f"{kernel} (the M={M} launch w4a16_gemm_packed_f16 makes on "
+                  + ("the whole layer)" if p == 1 else f"this rank's [{K}, {n_local}] column shard)"),
         "bound": "mfma",
         "achieved": flops_launch / col_us * 1e-6,
         "peak": PEAK_F16_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flops_launch / col_us * 1e-6 / PEAK_F16_TFLOPS,
-        "traffic": traffic.get("m128_hbm_bytes_per_launch") if p == 1 else None,
+        "traffic": traffic_of(traffic, "m128", kernel) if p == 1 else None,
         "traffic_source": traffic.get("source") if p == 1 else None,
         "algorithmic_bytes": algorithmic_bytes(M, K, n_local, G),
         "launch_us": col_us,
@@ -441,23 +469,47 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_sweep:
             sweep = {}
-            for m in (1, 8, 16, 32, 128, 512):
+            # the stock-layout kernel (w4a16_gemm_f16): what a call costs when no packed copy can be made
+            # (first call on a weight while the stream is being captured)
+            stock = [make_weights(K, N, G, seed=i, device=device) for i in range(4)]
+            for m in sorted({1} | {int(v) for v in args.sweep_ms.split(",")}):
                 xm = make_x(m, K, seed=m, device=device)
+                n_l = launches if m <= 512 else NBUF
                 us = time_launches([(lambda i=i: ops.awq_gemm_packed(xm, col[i])) for i in range(NBUF)], stream,
-                                   launches, args.warmup)
+                                   n_l, args.warmup if m <= 512 else NBUF)
                 by, fl = algorithmic_bytes(m, K, N, G), 2.0 * m * K * N
-                sweep[str(m)] = {"us": us, "GBps": by / us * 1e-3, "TFLOPs": fl / us * 1e-6,
-                                 "hbm_frac": by / us * 1e-3 / PEAK_HBM_GBPS, "mfma_frac": fl / us * 1e-6 / PEAK_F16_TFLOPS}
+                sweep[str(m)] = {"kernel": launch_shape(m, K, N), "us": us, "GBps": by / us * 1e-3,
+                                 "TFLOPs": fl / us * 1e-6, "hbm_frac": by / us * 1e-3 / PEAK_HBM_GBPS,
+                                 "mfma_frac": fl / us * 1e-6 / PEAK_F16_TFLOPS}
+                if m in (1, 16, 128):
+                    sweep[str(m)]["stock_layout_kernel_us"] = time_launches(
+                        [(lambda w=w: ops.awq_gemm_stock(xm, *w)) for w in stock], stream, 32, 8)
+            del stock
             out["sweep"] = sweep
             m1 = sweep["1"]
+            # floor of the decode launch on this machine: one pass of 16-byte loads over buffers of the
+            # layer's packed size, rotated like the weight sets, nothing else in the kernel
+            nbytes = col[0].packed_w.numel() * col[0].packed_w.element_size() \
+                + col[0].packed_sz.numel() * col[0].packed_sz.element_size()
+            bufs = [torch.randint(0, 255, (nbytes, ), dtype=torch.uint8, device=device) for _ in range(NBUF)]
+            sink = torch.zeros((4096, ), dtype=torch.int32, device=device)
+
+            def read_all(b):
+                check(lib.w4a16_stream_read(b.data_ptr(), nbytes, sink.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "w4a16_stream_read")
+            floor_us = time_launches([(lambda b=b: read_all(b)) for b in bufs], stream, launches, args.warmup)
+            del bufs
             out["roofline_m1"] = {
-                "kernel": "gemm_packed_kernel<1,3,16> (the M=1 launch w4a16_gemm_packed_f16 makes)",
+                "kernel": f"{launch_shape(1, K, N)} (the M=1 launch w4a16_gemm_packed_f16 makes)",
+                "streaming_floor_us": floor_us,
+                "streaming_floor_GBps": nbytes / floor_us * 1e-3,
+                "frac_of_streaming_floor": floor_us / m1["us"],
                 "bound": "hbm",
                 "achieved": m1["GBps"],
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": m1["hbm_frac"],
-                "traffic": traffic.get("m1_hbm_bytes_per_launch"),
+                "traffic": traffic_of(traffic, "m1", launch_shape(1, K, N)),
                 "algorithmic_bytes": algorithmic_bytes(1, K, N, G),
                 "launch_us": m1["us"],
             }

@@ -218,6 +218,27 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
+ * Which kernel and launch shape w4a16_gemm_packed_f16 / _batched / _ex pick by themselves for a problem
+ * (pure host arithmetic; for benchmarks, profiles and tests that need to name what ran).  No counterpart
+ * in the reference, whose launch shape is fixed (gemm_kernels.cu:422-444).
+ *   shape[0]  kernel: one of W4A16_KERNEL_*
+ *   shape[1..4]  STREAMING   (mt, t, waves, 0)      16-row / 16-column tiles, `waves` wavefronts split K
+ *                LDS_STAGED  (mt, t, nw, kw)        16-row / 16-column tiles
+ *                MFMA32      (mt, t, 1, kw)         32-row / 32-column tiles, private slabs per wavefront
+ *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
+ */
+enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFMA32 = 2, W4A16_KERNEL_MFMA32_SHARED = 3 };
+int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5]);
+
+/*
+ * Measurement aid: one pass of 16-byte non-temporal loads over `bytes` bytes at `src` (16-byte aligned),
+ * nothing else; `sink` is a device buffer of at least 8 KiB that is (practically) never written.  Its
+ * duration on a buffer of a layer's packed size is the floor for that layer's decode launch on the same
+ * machine.  No counterpart in the reference.
+ */
+int w4a16_stream_read(const void* src, size_t bytes, void* sink, void* stream);
+
+/*
  * out[K, N] fp16 from the private format (bit-identical to w4a16_dequantize_f16
  * on the tensors the buffers were packed from).
  */

@@ -68,11 +68,22 @@ for k in sorted(fetch):
     w_kib = write.get(k, (0.0, 0))[0]
     traffic["kernels"][k] = {"launches": n, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
                              "hbm_bytes_per_launch": (2 * f_kib + w_kib) * 1024}
-# the two launches bench.py reports rooflines for
-for key, pat in (("m128_hbm_bytes_per_launch", r"gemm_tiled_kernel<4, 3, 2, 4"), ("m1_hbm_bytes_per_launch", r"gemm_packed_kernel<1, 3, 16")):
+# the two launches bench.py reports rooflines for, under the names the library gives them
+sys.path.insert(0, ROOT)
+from vllm_quick_amd._lib import launch_shape  # noqa: E402  (host arithmetic only)
+
+for key, m in (("m128", 128), ("m1", 1)):
+    want = launch_shape(m, 4096, 11008)
     for k, v in traffic["kernels"].items():
-        if re.match(pat, k):
-            traffic[key] = v["hbm_bytes_per_launch"]
+        if k.replace(" ", "").startswith(want[:-1] + ","):
+            traffic[f"{key}_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
+            traffic[f"{key}_kernel"] = want
+import subprocess  # noqa: E402
+
+traffic["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                   text=True).stdout.strip()
+traffic["dirty"] = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "vllm_quick_amd/csrc"],
+                                       capture_output=True, text=True).stdout.strip())
 traffic["source"] = f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on bench.py)"
 for name in (f"{tag}_traffic.json", "traffic.json"):
     with open(os.path.join(out_dir, name), "w") as f:

@@ -44,6 +44,8 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16_masked": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                      [c_int] * 6 + [c_void_p, c_int, c_void_p]),
     "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "w4a16_launch_shape": (c_int, [c_int] * 5 + [ctypes.POINTER(c_int)]),
+    "w4a16_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
 }
 
 # Return codes that mirror the reference's std::invalid_argument (-> ValueError).
@@ -69,6 +71,18 @@ def _load() -> ctypes.CDLL:
 
 
 lib = _load()
+
+
+KERNEL_NAMES = {0: "gemm_packed_kernel", 1: "gemm_tiled_kernel", 2: "gemm_wide_kernel", 3: "gemm_wide_shared_kernel"}
+
+
+def launch_shape(M: int, K: int, N: int, batch: int = 1, epilogue: int = 0) -> str:
+    """The kernel and template arguments the library picks for a problem, as rocprof prints them."""
+    buf = (c_int * 5)()
+    check(lib.w4a16_launch_shape(M, K, N, batch, epilogue, buf), "launch_shape")
+    kind, mt, t, a, b = list(buf)
+    args = {0: (mt, t, a), 1: (mt, t, a, b), 2: (mt, t, b), 3: (mt, t, a)}[kind]
+    return f"{KERNEL_NAMES[kind]}<{','.join(str(v) for v in args)}>"
 
 
 def check(code: int, what: str) -> None:

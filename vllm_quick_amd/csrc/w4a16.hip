@@ -1556,6 +1556,24 @@ __global__ void __launch_bounds__(256) dequant_packed_kernel(const uint32_t* __r
   }
 }
 
+// Measurement aid: reads `n16` 16-byte words once, as the GEMM kernels read their weights (one 1-KiB
+// wave-instruction after another, non-temporal), and keeps one xor of them per workgroup so that the loads
+// cannot be dropped.  Its duration on a buffer of a layer's size is the floor for that layer's decode launch.
+__global__ void __launch_bounds__(256) stream_read_kernel(const u32x4* __restrict__ src, size_t n16,
+                                                          uint32_t* __restrict__ sink) {
+  u32x4 acc = u32x4{0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+  const uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (v == 0x9e3779b9u) sink[blockIdx.x] = v;  // practically never: the data decides, so the loads stay
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -2260,6 +2278,32 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
   if (active_hint < 0) return W4A16_E_SHAPE;
   return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
                              N, G, batch, epilogue, 0, 0, 0, 0, stream, problem_mask, active_hint);
+}
+
+int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5]) {
+  if (!shape) return W4A16_E_NULL;
+  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
+  const Choice c = choose_cfg(M, K, N, batch, epilogue == W4A16_EPI_SILU_MUL);
+  shape[1] = c.mt, shape[2] = c.t;
+  if (!c.tiled) {
+    shape[0] = W4A16_KERNEL_STREAMING, shape[3] = c.a, shape[4] = 0;
+  } else if (c.b > 0) {
+    shape[0] = W4A16_KERNEL_LDS_STAGED, shape[3] = c.a, shape[4] = c.b;
+  } else if (c.a > 1) {
+    shape[0] = W4A16_KERNEL_MFMA32_SHARED, shape[3] = c.a, shape[4] = 1;
+  } else {
+    shape[0] = W4A16_KERNEL_MFMA32, shape[3] = 1, shape[4] = -c.b;
+  }
+  return W4A16_OK;
+}
+
+int w4a16_stream_read(const void* src, size_t bytes, void* sink, void* stream) {
+  if (!src || !sink) return W4A16_E_NULL;
+  if (misaligned(src) || bytes < 16) return W4A16_E_ALIGN;
+  clear_stale_error();
+  hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const u32x4*>(src), bytes / 16, static_cast<uint32_t*>(sink));
+  return launched();
 }
 
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,
