@@ -166,6 +166,8 @@ def test_ragged_m(abi, cuda, M):
     tx, tqw, ts, tqz = [dev_t(a, cuda) for a in (x, qw, s, qz)]
     y = abi.gemm_packed(tx, abi.repack(tqw, ts, tqz))
     assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"M={M}")
+    # the stock-layout kernel: 16-, 32- and 64-row launch shapes, ragged last row block, ragged last 128 columns
+    assert_parity(abi.gemm_stock(tx, tqw, ts, tqz).cpu().numpy(), want, exact, strict=True, what=f"stock M={M}")
 
 
 CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 8), (1, 6, 8), (1, 1, 8), (1, 3, 8), (1, 8, 8), (1, 1, 4),
@@ -192,6 +194,9 @@ def test_every_launch_shape(abi, cuda, G):
     for cfg in CFGS:
         y = abi.gemm_packed(tx, packed, cfg=cfg)
         assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"G={G} cfg={cfg}")
+    for m in (3, 20, M):  # the three launch shapes of the stock-layout kernel at this group size
+        assert_parity(abi.gemm_stock(tx[:m].contiguous(), tqw, ts, tqz).cpu().numpy(), want[:m], exact[:m],
+                      strict=True, what=f"G={G} stock M={m}")
 
 
 @pytest.mark.parametrize("K,N,G", [(96, 40, 32), (160, 8, 32), (32, 16, 32), (224, 72, 32), (4096 + 128, 64, 128)])
@@ -283,6 +288,23 @@ def test_full_size_wide_kernel(abi, cuda, full, cfg):
         xe[i, k] = 1.0
     ye = abi.gemm_packed(dev_t(xe, cuda), full["packed"], cfg=cfg).cpu().numpy()
     assert (bits(ye) == bits(full["w"][ks])).all()
+
+
+def test_full_size_stock_layout_kernel(abi, cuda, full):
+    """The stock-layout kernel at 4096 x 11008: oracle parity at 1, 16, 32 and 100 rows, and unit rows, which
+    must return rows of the dequantised weights bit for bit (its row -> nibble transposition and its
+    column order)."""
+    for m in (1, 16, 32, 100):
+        x = orc.make_inputs(m, full["K"], full["N"], full["G"], seed=4200 + m)[0]
+        y = abi.gemm_stock(dev_t(x, cuda), full["tqw"], full["ts"], full["tqz"]).cpu().numpy()
+        assert_parity_slack(y, *reference_arithmetic(x, full["w"]), what=f"stock M={m}")
+    ks = [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 31, 32, 63, 64, 127, 128, 2047, 4095, 1234, 3210, 999, 65, 4000]
+    xe = np.zeros((len(ks), full["K"]), np.float16)
+    for i, k in enumerate(ks):
+        xe[i, k] = 1.0
+    for m in (len(ks), 16):
+        ye = abi.gemm_stock(dev_t(xe[:m], cuda), full["tqw"], full["ts"], full["tqz"]).cpu().numpy()
+        assert (bits(ye) == bits(full["w"][ks[:m]])).all()
 
 
 def test_full_size_dequantize_bit_exact(abi, full):

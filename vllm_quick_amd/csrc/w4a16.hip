@@ -1368,58 +1368,129 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
 // ---------------------------------------------------------------------------
 // Shape-agnostic GEMM on the stock layout (no repack, no workspace)
 // ---------------------------------------------------------------------------
-// One thread owns one packed column word (8 output columns) for up to RB rows.
-template <int RB>
-__global__ void __launch_bounds__(64) gemm_stock_kernel(const f16* __restrict__ x,
-                                                        const uint32_t* __restrict__ qw,
-                                                        const f16* __restrict__ scales,
-                                                        const uint32_t* __restrict__ qz,
-                                                        f16* __restrict__ out, int M, int K,
-                                                        int N, int G) {
+// The stock layout keeps the 8 nibbles of a word on 8 different output columns of ONE k; the matrix
+// instruction wants 8 consecutive k of one column in a lane.  A lane therefore loads the same packed word
+// column from 8 rows and transposes the 8 x 8 nibbles in registers (three rounds of masked swaps, about 50
+// instructions per 64 weights): word j of the result holds 8 k of the column in nibble j, in the nibble
+// order the private format uses, so the conversion and its constants are the ones of the packed kernels and
+// the weights fed to the matrix cores are bit-identical to theirs.
+//
+// A wavefront owns 16 adjacent word columns (lane & 15) x the four k-octets of a 32-k step (lane >> 4), i.e.
+// 128 output columns as 8 matrix tiles whose 16 "rows" are 8 columns apart; tile j's accumulator register v
+// of lane (token, q) is output column 8 (16 bx + 4 q + v) + (column of nibble j), so a lane ends up with 8
+// adjacent columns per register index and stores 16 bytes.  The KW wavefronts of a workgroup split K and
+// add their accumulators pairwise through LDS (log2 KW rounds).
+template <int MT, int KW>
+__global__ void __launch_bounds__(KW * 64) gemm_stock_kernel(const f16* __restrict__ x,
+                                                             const uint32_t* __restrict__ qw,
+                                                             const f16* __restrict__ scales,
+                                                             const uint32_t* __restrict__ qz,
+                                                             f16* __restrict__ out, int M, int K,
+                                                             int N, int G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
   const int NC = N / 8;
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int m0 = blockIdx.y * RB;
-  if (c >= NC) return;
-  float acc[RB][8];
-#pragma unroll
-  for (int r = 0; r < RB; ++r)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+  const int c = min((int)blockIdx.x * 16 + i16, NC - 1);  // past the edge: a valid column, never stored
+  const int m0 = blockIdx.y * (16 * MT);
+  const DqConst dqc = make_dq_const();
 
-  const f16x2 sixteenth = f16x2{(f16)0.0625f, (f16)0.0625f};
-  for (int g = 0; g < K / G; ++g) {
-    const uint32_t zw = qz[(size_t)g * NC + c];
-    const u32x4 sw = *reinterpret_cast<const u32x4*>(scales + (size_t)g * N + 8 * c);
-    const uint32_t zt = zw >> 8;
-    const f16x2 z0 = as_h2((zw & kLoMask) | kMagic), z1 = as_h2((zw & kHiMask) | kMagic);
-    const f16x2 z2 = as_h2((zt & kLoMask) | kMagic), z3 = as_h2((zt & kHiMask) | kMagic);
-    const f16x2 s0 = as_h2(sw.x), s1 = as_h2(sw.y), s2 = as_h2(sw.z), s3 = as_h2(sw.w);
-    for (int k = g * G; k < (g + 1) * G; ++k) {
-      const uint32_t q = qw[(size_t)k * NC + c];
-      const uint32_t t = q >> 8;
-      const f16x2 d0 = (as_h2((q & kLoMask) | kMagic) - z0) * s0;
-      const f16x2 d1 = ((as_h2((q & kHiMask) | kMagic) - z1) * sixteenth) * s1;
-      const f16x2 d2 = (as_h2((t & kLoMask) | kMagic) - z2) * s2;
-      const f16x2 d3 = ((as_h2((t & kHiMask) | kMagic) - z3) * sixteenth) * s3;
-      const float wv[8] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y,
-                           (float)d2.x, (float)d2.y, (float)d3.x, (float)d3.y};
+  const f16* xp[MT];
+  bool xok[MT];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int m = m0 + r;
-        const float xv = (m < M) ? (float)x[(size_t)m * K + k] : 0.f;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + i16;
+    xok[mt] = m < M;
+    xp[mt] = x + (size_t)(xok[mt] ? m : 0) * K + 8 * q;
+  }
+  f32x4 acc[8][MT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(xv, wv[j], acc[r][j]);
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // nibble j of a stock word is logical column kCol[j] of its 8; row kCol[p] of the octet goes to nibble p
+  constexpr int kCol[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+  const int nsteps = K / 32;
+  const int per = (nsteps + KW - 1) / KW;
+  const int s_end = min(nsteps, (w + 1) * per);
+  int g_cur = -1;
+  SZ sz[8];
+  for (int s = w * per; s < s_end; ++s) {
+    const int k0 = s * 32 + 8 * q;
+    uint32_t r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) r[p] = __builtin_nontemporal_load(qw + (size_t)(k0 + kCol[p]) * NC + c);
+    f16x8 xf[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      xf[mt] = *reinterpret_cast<const f16x8*>(xp[mt] + s * 32);
+      if (!xok[mt]) xf[mt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const int g = (s * 32) / G;
+    if (g != g_cur) {  // uniform over the wavefront
+      g_cur = g;
+      const uint32_t zw = qz[(size_t)g * NC + c];
+      const u32x4 sc = *reinterpret_cast<const u32x4*>(scales + (size_t)g * N + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t z = (zw >> (4 * j)) & 0xfu;
+        const uint32_t sbits = (sc[kCol[j] >> 1] >> (16 * (kCol[j] & 1))) & 0xffffu;
+        sz[j] = expand_sz(sbits | ((0xE400u | z) << 16));  // fp16 -(1024 + z), as the packer writes it
       }
     }
+    // 8 x 8 nibble transpose: swap the off-diagonal blocks of size 4, 2, 1
+#pragma unroll
+    for (int b = 4; b >= 1; b >>= 1) {
+      const uint32_t mask = b == 4 ? 0x0000ffffu : b == 2 ? 0x00ff00ffu : 0x0f0f0f0fu;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i & b) continue;
+        const uint32_t t = ((r[i] >> (4 * b)) ^ r[i + b]) & mask;
+        r[i + b] ^= t;
+        r[i] ^= t << (4 * b);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f16x8 af = dequant_word(r[j], sz[j], dqc);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[mt], acc[j][mt], 0, 0, 0);
+    }
   }
+
+  // pairwise sums over the K split: the upper half of the live wavefronts parks, the lower half adds
+  f32x4* park = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    const int m = m0 + r;
-    if (m < M) {
-      f16x8 h;
+  for (int half = KW / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (f16)acc[r][j];
-      *reinterpret_cast<f16x8*>(out + (size_t)m * N + 8 * c) = h;
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) park[((w - half) * 8 * MT + j * MT + mt) * 64 + lane] = acc[j][mt];
+    }
+    __syncthreads();
+    if (w < half) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[j][mt] += park[(w * 8 * MT + j * MT + mt) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (w != 0) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + i16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int cw = blockIdx.x * 16 + 4 * q + v;
+      if (m < M && cw < NC) {
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[kCol[j]] = (f16)acc[j][mt][v];
+        *reinterpret_cast<f16x8*>(out + (size_t)m * N + 8 * cw) = h;
+      }
     }
   }
 }
@@ -2100,19 +2171,30 @@ int w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const
   if (misaligned(scales) || misaligned(out)) return W4A16_E_ALIGN;
   clear_stale_error();
   const hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 block(64);
-  const int NC = N / 8;
-  if (M >= 4) {
-    const dim3 grid(ceil_div(NC, 64), ceil_div(M, 4));
-    hipLaunchKernelGGL(gemm_stock_kernel<4>, grid, block, 0, s, (const f16*)x,
-                       (const uint32_t*)qweight, (const f16*)scales, (const uint32_t*)qzeros,
-                       (f16*)out, M, K, N, G);
-  } else {
-    const dim3 grid(ceil_div(NC, 64), M);
-    hipLaunchKernelGGL(gemm_stock_kernel<1>, grid, block, 0, s, (const f16*)x,
-                       (const uint32_t*)qweight, (const f16*)scales, (const uint32_t*)qzeros,
-                       (f16*)out, M, K, N, G);
-  }
+  const int gx = ceil_div(N / 8, 16);
+#define W4A16_STOCK(MT_, KW_)                                                                              \
+  do {                                                                                                     \
+    constexpr int lds = (KW_ / 2) * 8 * MT_ * 1024;                                                        \
+    static_assert(lds <= 160 * 1024, "LDS budget");                                                        \
+    if (lds > 64 * 1024) {                                                                                 \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stock_kernel<MT_, KW_>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);           \
+      if (e != hipSuccess) {                                                                               \
+        g_last_hip_error = (int)e;                                                                         \
+        return W4A16_E_LAUNCH;                                                                             \
+      }                                                                                                    \
+    }                                                                                                      \
+    hipLaunchKernelGGL((gemm_stock_kernel<MT_, KW_>), dim3(gx, ceil_div(M, 16 * MT_)), dim3(KW_ * 64), lds, s, \
+                       (const f16*)x, (const uint32_t*)qweight, (const f16*)scales, (const uint32_t*)qzeros,  \
+                       (f16*)out, M, K, N, G);                                                             \
+  } while (0)
+  if (M <= 16)
+    W4A16_STOCK(1, 16);
+  else if (M <= 32)
+    W4A16_STOCK(2, 8);
+  else
+    W4A16_STOCK(4, 8);
+#undef W4A16_STOCK
   return launched();
 }
 
