@@ -28,7 +28,12 @@
  * p2p_ar_all_reduce() calls (same element count and type).  Calls of one context must be
  * stream-ordered with respect to each other.  A rank that waits longer than the context's
  * timeout for a peer stops waiting, leaves an unspecified result and raises the context's
- * sticky status flag (p2p_ar_status); it never spins without bound.
+ * sticky status flag; it never spins without bound.  The flag also lives in host memory the
+ * kernel writes directly, so the host sees it without synchronising: every later
+ * p2p_ar_all_reduce() of the context fails with P2P_AR_E_TIMEOUT until the flag is cleared
+ * (p2p_ar_status with clear != 0), and p2p_ar_poll() reads it at any time.  (The reference's
+ * kernels spin until the peer arrives, custom_all_reduce.cuh:144-178: a late rank delays the
+ * others; here it is reported once the timeout, 5 minutes unless set, has passed.)
  *
  * Return value: 0 on success, a negative P2P_AR_E* code otherwise.
  */
@@ -42,7 +47,7 @@
 extern "C" {
 #endif
 
-#define P2P_AR_ABI_VERSION 1
+#define P2P_AR_ABI_VERSION 2
 #define P2P_AR_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
 
 enum {
@@ -53,7 +58,8 @@ enum {
   P2P_AR_E_ALIGN = -4,     /* input or output not 16-byte aligned                                             */
   P2P_AR_E_DTYPE = -5,     /* element type not f32 / f16 / bf16 (custom_all_reduce.cu:95-97)                  */
   P2P_AR_E_HIP = -6,       /* a HIP runtime call failed; see p2p_ar_last_hip_error()                          */
-  P2P_AR_E_STATE = -7      /* context not connected yet, connected twice, or its GPU is not the current device */
+  P2P_AR_E_STATE = -7,     /* context not connected yet, connected twice, or its GPU is not the current device */
+  P2P_AR_E_TIMEOUT = -8    /* an earlier kernel of this context gave up waiting for a peer: its result is invalid */
 };
 
 enum { P2P_AR_F32 = 0, P2P_AR_F16 = 1, P2P_AR_BF16 = 2 };
@@ -109,8 +115,15 @@ void* p2p_ar_mailbox_ptr(void* ctx);
  */
 int p2p_ar_all_reduce(void* ctx, const void* in, void* out, int64_t numel, int dtype, void* stream);
 
-/* How long a kernel waits for a peer before it gives up (default 10000 ms). */
+/* How long a kernel waits for a peer before it gives up (default 300000 ms). */
 int p2p_ar_set_timeout_ms(void* ctx, int ms);
+
+/*
+ * Reads the host copy of the sticky status flag: no device call, no synchronisation, may be called
+ * at any time (also while kernels of the context run or a stream is being captured).  *timed_out = 1
+ * once a kernel that gave up has written the flag; a kernel still waiting has not.
+ */
+int p2p_ar_poll(void* ctx, int* timed_out);
 
 /*
  * Synchronous read of the sticky status flag: *timed_out = 1 if any kernel of this context gave

@@ -212,6 +212,93 @@ def test_multi_process_all_reduce_on_one_gpu(world):
         assert status == "ok", f"rank {rank}:\n{status}"
 
 
+def _late_worker(rank, world, port, q):
+    """Rank 1 arrives 1.5 s late at the first all-reduce; rank 0 waits 0.3 s at most."""
+    try:
+        import time
+        sys.path.insert(0, ROOT)
+        from vllm_quick_amd.parallel_utils import communication_op as comm
+        from vllm_quick_amd.parallel_utils import custom_all_reduce as car
+        from vllm_quick_amd.parallel_utils import parallel_state as ps
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ps.initialize_model_parallel(world)
+        car.init_custom_ar()
+        fa = car.get_handle()
+        assert fa is not None
+        fa.set_timeout_ms(300 if rank == 0 else 20000)
+        x = torch.full((4096, ), float(rank + 1), dtype=torch.float16, device=dev)
+        dist.barrier()
+        if rank == 1:
+            time.sleep(1.5)
+        y = comm.tensor_model_parallel_all_reduce(x)  # returns at once: the kernel is what waits
+        torch.cuda.synchronize()
+        if rank == 0:
+            # the result is invalid, and every way of asking says so
+            with pytest.raises(RuntimeError, match="gave up waiting"):
+                fa.check_health()
+            with pytest.raises(RuntimeError, match="gave up waiting"):
+                comm.tensor_model_parallel_all_reduce(x)  # nothing launched: the call sequence stays aligned
+            with pytest.raises(RuntimeError, match="gave up waiting"):
+                with car.capture():
+                    pass
+            assert fa.timed_out(clear=True)
+            fa.check_health()  # cleared
+        else:
+            # the late rank found rank 0's contribution waiting in its mailbox
+            assert torch.equal(y, torch.full_like(y, 3.0))
+            fa.check_health()
+        dist.barrier()
+        # both ranks made call 1, so call 2 pairs up again
+        fa.set_timeout_ms(20000)
+        y = comm.tensor_model_parallel_all_reduce(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y, torch.full_like(y, 3.0))
+        # destroy_custom_ar() reports a flag nobody has cleared
+        dist.barrier()
+        if rank == 1:
+            time.sleep(1.0)
+        fa.set_timeout_ms(300 if rank == 0 else 20000)
+        comm.tensor_model_parallel_all_reduce(x)
+        torch.cuda.synchronize()
+        if rank == 0:
+            with pytest.raises(RuntimeError, match="gave up waiting"):
+                car.destroy_custom_ar()
+            assert car.get_handle() is None
+        else:
+            car.destroy_custom_ar()
+        ps.destroy_model_parallel()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except BaseException:  # noqa: BLE001 - pytest.raises failures are not Exceptions
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+def test_a_late_peer_raises_on_the_waiting_rank():
+    """A rank delayed past the timeout: the rank that gave up gets a RuntimeError at its next all-reduce,
+    from check_health(), at the exit of capture() and from destroy_custom_ar(); after the flag is cleared
+    the two ranks pair up again."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        results = [q.get(timeout=120) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, status in results:
+        assert status == "ok", f"rank {rank}:\n{status}"
+
+
 def test_two_contexts_in_one_process():
     """Both ranks in this process, connected by plain device pointers, one stream each."""
     from vllm_quick_amd import _p2p_lib as P
@@ -283,10 +370,15 @@ def test_a_missing_peer_ends_in_a_status_flag_not_a_hang():
         torch.cuda.synchronize()
         waited = time.perf_counter() - t0
         assert 0.25 < waited < 5.0, f"gave up after {waited:.3f} s, timeout was 0.3 s"
+        P.check(L.p2p_ar_poll(ctxs[0], ctypes.byref(flag)), "poll")
+        assert flag.value == 1, "the host copy of the flag must be set once the kernel has ended"
+        assert L.p2p_ar_all_reduce(ctxs[0], x.data_ptr(), y.data_ptr(), x.numel(), P.F16, None) == P.E_TIMEOUT
         P.check(L.p2p_ar_status(ctxs[0], ctypes.byref(flag), 1), "status")
         assert flag.value == 1
         P.check(L.p2p_ar_status(ctxs[0], ctypes.byref(flag), 0), "status")
         assert flag.value == 0, "clear must reset the sticky flag"
+        P.check(L.p2p_ar_poll(ctxs[0], ctypes.byref(flag)), "poll")
+        assert flag.value == 0, "and its host copy"
     finally:
         torch.cuda.synchronize()
         for c in ctxs:

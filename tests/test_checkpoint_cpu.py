@@ -140,3 +140,18 @@ def test_load_stacked_weights_matches_slicing_by_hand(ckpt_dir, monkeypatch, tp,
     with pytest.raises(KeyError):
         WU.load_stacked_weights(model, [("layers.9.mlp.down_proj.qweight", torch.zeros(1))])
     assert WU.load_stacked_weights(model, [("layers.9.mlp.down_proj.qweight", torch.zeros(1))], strict=False) == []
+
+
+def test_a_loader_call_bumps_the_write_counter_by_exactly_one():
+    # the packed copy of a layer's weights is keyed on this counter: one bump per load, not one per row
+    p = torch.nn.Parameter(torch.zeros(4, 3), requires_grad=False)
+    before = p._version
+    WU.default_weight_loader(p, torch.ones(4, 3))
+    assert p._version == before + 1 and bool((p == 1).all())
+    L.mark_written(p)
+    assert p._version == before + 2
+    # a 0-d parameter (no rows to walk) loads too
+    s = torch.nn.Parameter(torch.zeros(()), requires_grad=False)
+    before = s._version
+    WU.default_weight_loader(s, torch.tensor(2.5))
+    assert s._version == before + 1 and float(s) == 2.5

@@ -122,6 +122,49 @@ def test_few_tokens_skip_the_experts_nobody_selected(monkeypatch):
     assert np.allclose(y2.float().numpy(), y.float().numpy(), rtol=1e-2, atol=2e-3)
 
 
+def test_stamp_cache_and_invalidation(monkeypatch):
+    from vllm_quick_amd.layers.linear import mark_written
+    moe, fake = make(monkeypatch)
+    fill(moe, seed=21)
+    x = torch.from_numpy((np.random.default_rng(1).standard_normal((1, 3, 64)) * 0.5).astype(np.float16))
+    count = lambda: [t[0] for t in fake.trace].count("repack_batch")  # noqa: E731
+    moe(x), moe(x)
+    assert count() == 2
+    # a loader write that changes nothing the stamp sees but the epoch: full look, same tensors, no re-layout
+    mark_written(moe.gate.weight)
+    moe(x)
+    assert count() == 2
+    # a loader write into an expert tensor: re-layout
+    lin = moe.experts[2].w1
+    lin.qweight.data.copy_(lin.qweight.data)
+    mark_written(lin.qweight)
+    moe(x)
+    assert count() == 4
+    # a tensor swapped behind the counters' back needs invalidate()
+    lin.scales.data = lin.scales.data.clone()
+    moe(x)
+    assert count() == 4
+    moe.invalidate()
+    moe(x)
+    assert count() == 6
+
+
+def test_both_routes_combine_the_experts_the_same_way(monkeypatch):
+    """The batched route and the per-expert loop (taken when no re-layout is possible, e.g. the first call
+    under a graph capture) scale each expert's output in fp16 and sum in fp32, rounding once: the same
+    values up to the order of an fp32 sum."""
+    moe, fake = make(monkeypatch)
+    fill(moe, seed=31)
+    moe.sparse_max_tokens = 0
+    x = torch.from_numpy((np.random.default_rng(2).standard_normal((1, 7, 64)) * 0.5).astype(np.float16))
+    batched = moe(x)
+    moe.batched = False
+    looped = moe(x)
+    a, b = batched.float().numpy(), looped.float().numpy()
+    ulp = np.maximum(np.abs(a), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(a - b) <= ulp).all()
+
+
 def test_separate_activation_route(monkeypatch):
     moe, fake = make(monkeypatch)
     assert moe.fuse_act  # K of w2 is a multiple of the group size, hence of 16: always tile-aligned

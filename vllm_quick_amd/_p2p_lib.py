@@ -14,7 +14,7 @@ import torch  # noqa: F401  (first, so that this library binds to PyTorch's HIP 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_AR_LIBRARY") or os.path.join(_HERE, "csrc", "libp2p_ar.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 IPC_HANDLE_BYTES = 64
 F32, F16, BF16 = 0, 1, 2
 DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -34,10 +34,12 @@ SYMBOLS = {
     "p2p_ar_all_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "p2p_ar_set_timeout_ms": (c_int, [c_void_p, c_int]),
     "p2p_ar_status": (c_int, [c_void_p, POINTER(c_int), c_int]),
+    "p2p_ar_poll": (c_int, [c_void_p, POINTER(c_int)]),
     "p2p_ar_destroy": (c_int, [c_void_p]),
 }
 
 _VALUE_ERRORS = {-1, -3, -4, -5}
+E_TIMEOUT = -8
 
 
 def _load() -> ctypes.CDLL:

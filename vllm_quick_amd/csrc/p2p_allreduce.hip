@@ -21,7 +21,9 @@
 // finished call e-1), and call e+1 uses the other half.
 //
 // Every wait is bounded (wall clock and an iteration cap): a rank whose peer never arrives sets
-// the sticky status word and carries on, so a kernel of this library always terminates.
+// the sticky status word, in device memory and in a pinned host word the host reads without
+// synchronising, and carries on, so a kernel of this library always terminates and the host learns
+// of the invalid result at its next call.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -38,7 +40,7 @@ constexpr int kMaxBlocks = 64;
 constexpr int kThreads = 512;
 constexpr int kOneStageBlocks = 32;
 constexpr int64_t kFlagBytes = 2 * 2 * kMaxRanks * kMaxBlocks * 4;
-constexpr unsigned kSpinCap = 1u << 26;
+constexpr unsigned long long kSpinCap = 1ull << 34;  // backstop only: hours; the wall clock decides
 
 thread_local int g_last_hip_error = 0;
 
@@ -49,7 +51,9 @@ struct Ctx {
   char* peers[kMaxRanks] = {};
   bool opened[kMaxRanks] = {};
   uint32_t* state = nullptr;  // device: [0] calls completed, [1] workgroups done in this call, [2] status
-  long long timeout_ticks = 10000LL * 100000;  // wall_clock64() ticks at 100 MHz
+  uint32_t* host_flag = nullptr;      // pinned, mapped: the status word as the host reads it
+  uint32_t* host_flag_dev = nullptr;  // the same word as the kernels address it
+  long long timeout_ticks = 300000LL * 100000;  // wall_clock64() ticks at 100 MHz
   bool connected = false;
 };
 
@@ -58,6 +62,7 @@ struct ArArgs {
   uint4* out;
   char* mbox[kMaxRanks];
   uint32_t* state;
+  uint32_t* host_flag;
   long long units;       // 16-byte units in the vector
   long long region_bytes, half_bytes;
   long long timeout_ticks;
@@ -162,11 +167,12 @@ __device__ inline void signal_and_wait(const ArArgs& a, int half, int stage, uin
                        __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t* mine = flag_ptr(a.mbox[a.rank], half, stage, t, blockIdx.x);
     const long long t0 = wall_clock64();
-    unsigned spins = 0;
+    unsigned long long spins = 0;
     while (static_cast<int>(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
       ++spins;
       if (spins > kSpinCap || ((spins & 63u) == 0 && wall_clock64() - t0 > a.timeout_ticks)) {
         a.state[2] = 1;  // gave up: sticky, read by p2p_ar_status()
+        __hip_atomic_store(a.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // and by p2p_ar_poll()
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -327,6 +333,7 @@ const char* p2p_ar_strerror(int code) {
     case P2P_AR_E_ALIGN: return "input and output must be 16-byte aligned";
     case P2P_AR_E_DTYPE: return "custom allreduce only supports float32, float16 and bfloat16";
     case P2P_AR_E_HIP: return "a HIP runtime call failed";
+    case P2P_AR_E_TIMEOUT: return "an earlier all-reduce of this context gave up waiting for a peer; its result is invalid";
     case P2P_AR_E_STATE: return "context is not connected to its peers (or already is), or its GPU is not the current device";
   }
   return "unknown error code";
@@ -365,10 +372,16 @@ int p2p_ar_create(int rank, int world, int64_t max_bytes, void** ctx_out) {
   if (err == hipSuccess) err = hipMemset(c->mailbox, 0, c->mailbox_bytes);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&c->state), 64);
   if (err == hipSuccess) err = hipMemset(c->state, 0, 64);
+  if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&c->host_flag), 64, hipHostMallocMapped);
+  if (err == hipSuccess) {
+    *c->host_flag = 0;
+    err = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_flag_dev), c->host_flag, 0);
+  }
   if (err == hipSuccess) err = hipDeviceSynchronize();
   if (err != hipSuccess) {
     if (c->mailbox) (void)hipFree(c->mailbox);
     if (c->state) (void)hipFree(c->state);
+    if (c->host_flag) (void)hipHostFree(c->host_flag);
     delete c;
     return hip_fail(err);
   }
@@ -432,12 +445,14 @@ int p2p_ar_all_reduce(void* ctx, const void* in, void* out, int64_t numel, int d
   int dev = -1;
   HIP_TRY(hipGetDevice(&dev));
   if (dev != c->device) return P2P_AR_E_STATE;  // the mailbox and the call counter live on the context's GPU
+  if (*static_cast<volatile uint32_t*>(c->host_flag)) return P2P_AR_E_TIMEOUT;
 
   ArArgs a;
   a.in = static_cast<const uint4*>(in);
   a.out = static_cast<uint4*>(out);
   for (int r = 0; r < kMaxRanks; ++r) a.mbox[r] = c->peers[r];
   a.state = c->state;
+  a.host_flag = c->host_flag_dev;
   a.units = bytes / 16;
   a.region_bytes = c->region_bytes;
   a.half_bytes = c->half_bytes;
@@ -471,7 +486,17 @@ int p2p_ar_status(void* ctx, int* timed_out, int clear) {
   uint32_t v = 0;
   HIP_TRY(hipMemcpy(&v, c->state + 2, 4, hipMemcpyDeviceToHost));
   *timed_out = v != 0;
-  if (clear && v) HIP_TRY(hipMemset(c->state + 2, 0, 4));
+  if (*static_cast<volatile uint32_t*>(c->host_flag)) *timed_out = 1;
+  if (clear) {
+    if (v) HIP_TRY(hipMemset(c->state + 2, 0, 4));
+    *static_cast<volatile uint32_t*>(c->host_flag) = 0;
+  }
+  return P2P_AR_OK;
+}
+
+int p2p_ar_poll(void* ctx, int* timed_out) {
+  if (!ctx || !timed_out) return P2P_AR_E_NULL;
+  *timed_out = *static_cast<volatile uint32_t*>(static_cast<Ctx*>(ctx)->host_flag) != 0;
   return P2P_AR_OK;
 }
 
@@ -484,6 +509,7 @@ int p2p_ar_destroy(void* ctx) {
     if (c->opened[r] && hipIpcCloseMemHandle(c->peers[r]) != hipSuccess) rc = P2P_AR_E_HIP;
   if (c->mailbox && hipFree(c->mailbox) != hipSuccess) rc = P2P_AR_E_HIP;
   if (c->state && hipFree(c->state) != hipSuccess) rc = P2P_AR_E_HIP;
+  if (c->host_flag && hipHostFree(c->host_flag) != hipSuccess) rc = P2P_AR_E_HIP;
   delete c;
   return rc;
 }

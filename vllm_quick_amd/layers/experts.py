@@ -33,7 +33,7 @@ import torch.nn.functional as F
 from .._C import ops
 from ..parallel_utils.communication_op import tensor_model_parallel_all_reduce
 from ..parallel_utils.parallel_state import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size)
-from .linear import LinearMethodBase, ReplicatedLinear
+from .linear import LinearMethodBase, ReplicatedLinear, write_epoch
 from .quantization.awq import AWQLinearMethod
 
 
@@ -93,7 +93,8 @@ class MixtralMoE(torch.nn.Module):
         # one token selects top_k experts; 4 tokens of a top-2-of-8 router still leave a third of them idle,
         # beyond that the switch costs about what it saves
         self.sparse_max_tokens = 4
-        self._packed = None  # (stamp, fused?, w13 batch, w2 batch)
+        self._packed = None  # (quick stamp, w13 batch, w2 batch, full stamp)
+        self._watched: List[torch.Tensor] = []
 
     # ------------------------------------------------------------------
     def _stock(self, names):
@@ -104,12 +105,30 @@ class MixtralMoE(torch.nn.Module):
                 out.append((lin.qweight, lin.scales, lin.qzeros))
         return out
 
+    def invalidate(self) -> None:
+        """Forget the packed copy (after a write to an expert's tensors that neither went through a weight
+        loader nor bumped the tensor's in-place-write counter, e.g. `param.data = ...`)."""
+        self._packed = None
+
+    def _versions(self):
+        try:
+            return tuple(t._version for t in self._watched)
+        except RuntimeError:  # inference tensors keep no counter (and cannot be written in place)
+            return None
+
     def _batches(self):
         """The local experts' weights back to back in the private layout, rebuilt when any stock
-        tensor was written since (weight loading)."""
+        tensor was written since (weight loading).  The common case costs one integer comparison and one
+        pass over the tensors' write counters: the full look at every tensor (its address too) is taken
+        only after a weight loader has run."""
+        if self._packed is not None and self._packed[0] == (write_epoch(), self.fuse_act, self._versions()):
+            return self._packed[1], self._packed[2]
         w1, w3, w2 = self._stock(("w1", )), self._stock(("w3", )), self._stock(("w2", ))
-        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for trio in w1 + w3 + w2 for t in trio)
-        if self._packed is not None and self._packed[0] == (stamp, self.fuse_act):
+        flat = [t for trio in w1 + w3 + w2 for t in trio]
+        stamp = tuple((t.data_ptr(), ops.tensor_version(t)) for t in flat)
+        if self._packed is not None and self._packed[3] == (stamp, self.fuse_act):
+            self._watched = flat
+            self._packed = ((write_epoch(), self.fuse_act, self._versions()), ) + self._packed[1:]
             return self._packed[1], self._packed[2]
         if ops.stream_is_capturing():
             return None  # no re-layout inside a graph capture
@@ -121,7 +140,8 @@ class MixtralMoE(torch.nn.Module):
             merged = w1 + w3  # 2E problems: every w1, then every w3
         b13 = ops.awq_repack_batch(*[[trio[i] for trio in merged] for i in (0, 1, 2)])
         b2 = ops.awq_repack_batch(*[[trio[i] for trio in w2] for i in (0, 1, 2)])
-        self._packed = ((stamp, self.fuse_act), b13, b2)
+        self._watched = flat
+        self._packed = ((write_epoch(), self.fuse_act, self._versions()), b13, b2, (stamp, self.fuse_act))
         return b13, b2
 
     def routing(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -141,11 +161,14 @@ class MixtralMoE(torch.nn.Module):
         expert_weights = self.routing(hidden_states)  # [T, E_local]
         batches = self._batches() if self.batched else None
         if batches is None:
-            # the reference's loop (mixtral_quant.py:145-157)
-            final = None
+            # the reference's loop (mixtral_quant.py:145-157), with the sum over experts kept in fp32 and
+            # rounded once like the batched route below, so that one module gives the same values whichever
+            # route a call takes (the reference adds the fp16 products one by one)
+            acc = None
             for j, idx in enumerate(self.expert_indicies):
                 cur = self.experts[idx](hidden_states).mul_(expert_weights[:, j:j + 1])
-                final = cur if final is None else final.add_(cur)
+                acc = cur.float() if acc is None else acc.add_(cur)
+            final = acc.to(hidden_states.dtype)
         else:
             b13, b2 = batches
             E = len(self.expert_indicies)

@@ -103,11 +103,29 @@ def _copy_shard(dst: torch.Tensor, src: torch.Tensor, owner: Optional[torch.Tens
         mark_written(owner)
 
 
+# Counts the writes the weight loaders have made, process-wide: modules that keep a derived copy of many
+# tensors (the expert block) look at this one integer before they look at every tensor.
+_WRITE_EPOCH = [0]
+
+
+def write_epoch() -> int:
+    return _WRITE_EPOCH[0]
+
+
 def mark_written(param: torch.Tensor) -> None:
-    """Bump a tensor's in-place-write counter after a write that bypassed it (`param.data...`)."""
+    """Bump a tensor's in-place-write counter by one after a write that bypassed it (`param.data...`)."""
+    _WRITE_EPOCH[0] += 1
+    bump = getattr(torch._C, "_increment_version", None)
+    if bump is None:
+        return
     try:
-        torch._C._increment_version(param)
-    except (RuntimeError, AttributeError):  # inference tensors keep no counter
+        bump([param])  # current torch: an iterable of tensors (a bare tensor would be walked row by row)
+    except TypeError:
+        try:
+            bump(param)  # older torch: one tensor
+        except RuntimeError:
+            pass
+    except RuntimeError:  # inference tensors keep no counter
         pass
 
 

@@ -11,10 +11,19 @@ registered after capture, custom_all_reduce.py:192-200).  The kernels here WRITE
 library owns, so any device tensor can be an input: `register_buffer` and `register_graph_buffers`
 are kept for call-site compatibility and do nothing, and `all_reduce_reg` / `all_reduce_unreg` are
 the same launch.
+
+A late peer: the reference's kernels spin until every peer has arrived (custom_all_reduce.cuh:144-178).
+The kernels here stop waiting after the handle's timeout (5 minutes unless `VLLM_QUICK_P2P_AR_TIMEOUT_MS`
+or `set_timeout_ms` says otherwise) so that a GPU is never left with a kernel that cannot end; the result
+of such a call is invalid, and the kernel says so in a host-visible flag.  That flag turns into a
+RuntimeError at the next all-reduce of the handle (eager or while capturing), at the exit of `capture()`,
+in `destroy_custom_ar()` and wherever the caller asks with `get_handle().check_health()` - the call for a
+loop that replays captured graphs, after it has synchronised a step.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 from contextlib import contextmanager
 from typing import List, Optional
 
@@ -28,6 +37,8 @@ from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_p
 _CA_HANDLE: Optional["CustomAllreduce"] = None
 _IS_CAPTURING = False
 _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
+_TIMEOUT_ENV = "VLLM_QUICK_P2P_AR_TIMEOUT_MS"
+_DEFAULT_TIMEOUT_MS = 300000
 
 
 def init_custom_ar() -> None:
@@ -44,7 +55,41 @@ def init_custom_ar() -> None:
         return
     if not _can_p2p(rank, world_size):
         return
-    _CA_HANDLE = CustomAllreduce(rank, world_size)
+    handle = CustomAllreduce(rank, world_size)
+    if _self_check(handle):
+        _CA_HANDLE = handle
+    else:
+        # every rank took the same decision (the verdicts were gathered): the collective library stays the path
+        torch.cuda.synchronize()
+        dist.barrier(group=get_tensor_model_parallel_group())
+        handle.close()
+
+
+def _self_check(handle: "CustomAllreduce") -> bool:
+    """One all-reduce of a known pattern through each of the two algorithms, compared bit for bit with the
+    sum every rank can work out by itself; all ranks learn whether ALL of them saw the right answer.
+    (No counterpart in the reference; it guards the first use of a path whose memory model - peers
+    writing into uncached IPC-mapped memory - depends on the node.)"""
+    group = get_tensor_model_parallel_group()
+    world, rank = handle.world_size, handle.rank
+    ok = True
+    try:
+        handle.set_timeout_ms(30000)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # 8 KiB: one kernel stage for every world size; 2 MiB: two stages from 4 ranks on
+        for n in (4096, min(1 << 20, handle.max_size // 2)):
+            base = (torch.arange(n, device=dev, dtype=torch.int32) % 7).to(torch.float16)
+            got = handle.all_reduce_unreg(base + float(rank + 1))
+            want = base * world + float(world * (world + 1) // 2)  # small integers: exact in fp16
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(got, want))
+        ok = ok and not handle.timed_out(clear=True)
+        handle.set_timeout_ms(int(os.environ.get(_TIMEOUT_ENV) or _DEFAULT_TIMEOUT_MS))
+    except Exception:  # noqa: BLE001 - whatever went wrong, the collective library is the answer
+        ok = False
+    verdicts: List[Optional[bool]] = [None] * world
+    dist.all_gather_object(verdicts, ok, group=group)
+    return all(verdicts)
 
 
 def begin_capture() -> None:
@@ -72,8 +117,11 @@ def destroy_custom_ar() -> None:
         # a mailbox may go only when no peer can still be writing into it
         torch.cuda.synchronize()
         dist.barrier(group=get_tensor_model_parallel_group())
-        _CA_HANDLE.close()
-        _CA_HANDLE = None
+        handle, _CA_HANDLE = _CA_HANDLE, None
+        gave_up = handle.timed_out()
+        handle.close()
+        if gave_up:
+            raise RuntimeError(_GAVE_UP)
 
 
 @contextmanager
@@ -86,6 +134,7 @@ def capture():
         handle = get_handle()
         if handle is not None:
             handle.register_graph_buffers()
+            handle.check_health()
 
 
 def custom_all_reduce(input: torch.Tensor) -> Optional[torch.Tensor]:
@@ -126,6 +175,10 @@ def _is_weak_contiguous(t: torch.Tensor) -> bool:
                                  == t.numel() * t.element_size())
 
 
+_GAVE_UP = ("a peer-to-peer all-reduce gave up waiting for a peer (a rank arrived later than the timeout, "
+            "or not at all): the results since then are invalid")
+
+
 class CustomAllreduce:
 
     # max_size: max supported allreduce size
@@ -143,6 +196,8 @@ class CustomAllreduce:
         _p2p_lib.check(_p2p_lib.lib.p2p_ar_ipc_handle(self._ptr, mine), "ipc handle")
         handles = self._gather_ipc_meta(mine.raw)
         _p2p_lib.check(_p2p_lib.lib.p2p_ar_connect(self._ptr, b"".join(handles)), "open peer mailboxes")
+        if os.environ.get(_TIMEOUT_ENV):
+            self.set_timeout_ms(int(os.environ[_TIMEOUT_ENV]))
 
     def _gather_ipc_meta(self, shard_data):
         all_data = [None] * self.world_size
@@ -174,9 +229,11 @@ class CustomAllreduce:
         if not _is_weak_contiguous(out) or not _is_weak_contiguous(inp):
             raise ValueError("custom allreduce needs dense input and output tensors")
         stream = torch.cuda.current_stream(inp.device).cuda_stream
-        _p2p_lib.check(
-            _p2p_lib.lib.p2p_ar_all_reduce(self._ptr, inp.data_ptr(), out.data_ptr(), inp.numel(),
-                                           _p2p_lib.DTYPE_CODES[inp.dtype], stream), "custom_all_reduce")
+        rc = _p2p_lib.lib.p2p_ar_all_reduce(self._ptr, inp.data_ptr(), out.data_ptr(), inp.numel(),
+                                            _p2p_lib.DTYPE_CODES[inp.dtype], stream)
+        if rc == _p2p_lib.E_TIMEOUT:  # the host-visible flag of an earlier call: nothing was launched
+            raise RuntimeError(_GAVE_UP)
+        _p2p_lib.check(rc, "custom_all_reduce")
         return out
 
     # the two entry points of the reference (registered / unregistered input) are one launch here
@@ -188,6 +245,15 @@ class CustomAllreduce:
 
     def set_timeout_ms(self, ms: int) -> None:
         _p2p_lib.check(_p2p_lib.lib.p2p_ar_set_timeout_ms(self._ptr, ms), "set timeout")
+
+    def check_health(self) -> None:
+        """Raises RuntimeError if a kernel of this handle has given up waiting for a peer.  Reads host
+        memory only (no device call): cheap enough for every step, and legal while a stream is captured.
+        A kernel that is still running has not reported yet; synchronise first to be sure of a step."""
+        flag = ctypes.c_int(0)
+        _p2p_lib.check(_p2p_lib.lib.p2p_ar_poll(self._ptr, ctypes.byref(flag)), "poll")
+        if flag.value:
+            raise RuntimeError(_GAVE_UP)
 
     def timed_out(self, clear: bool = False) -> bool:
         """True if a kernel of this handle gave up waiting for a peer (synchronises the device)."""
