@@ -1,5 +1,7 @@
 """Tensor-parallel column/row sharding of the W4A16 linear, and the expert-parallel split of the
-mixture-of-experts block, with world_size 2 on the gloo backend.
+mixture-of-experts block, with world_size 2 and 4 on the gloo backend (at 4 ranks with 1376-column
+shards, the width an 8-way split of the 11008-wide benchmark layer gives each rank: 86 column tiles,
+not a multiple of any launch shape's tile count).
 
 Each rank builds the reference-style layers on top of AWQLinearMethod (native ops replaced by
 the oracle-backed fakes: there is no GPU here), loads its shard of one full checkpoint through
@@ -26,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N=192):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -65,12 +67,12 @@ def _worker(rank, world, port, q):
             assert ps.is_cupy_nccl_enabled_for_all_reduce()
             r = comm.tensor_model_parallel_all_reduce(torch.full((2, 2), float(rank + 1)))
         comm.rccl_utils.all_reduce = real
-        assert seen == [(2, 2)] and torch.equal(r, torch.full((2, 2), 3.0))
+        assert seen == [(2, 2)] and torch.equal(r, torch.full((2, 2), float(sum(range(1, world + 1)))))
         assert not ps.is_rccl_enabled_for_all_reduce()
         comm.tensor_model_parallel_all_reduce(torch.ones(2))
         assert seen == [(2, 2)]
 
-        M, K, N = 5, 128, 192
+        M, K = 5, 128
         x, qw, s, qz = orc.make_inputs(M, K, N, 32, seed=41)
         want = orc.gemm_faithful(x, qw, s, qz).astype(np.float32)
         ck = {"qweight": qw, "scales": s, "qzeros": qz}
@@ -103,8 +105,9 @@ def _worker(rank, world, port, q):
         from test_experts_cpu import fill, reference_block
         X.ops = awq_mod.ops
         moe = X.MixtralMoE(4, 2, 64, 96, linear_method=method, params_dtype=torch.float16)
-        assert moe.expert_indicies == [2 * rank, 2 * rank + 1]
-        assert [e is not None for e in moe.experts] == [i // 2 == rank for i in range(4)]
+        per = 4 // world
+        assert moe.expert_indicies == list(range(per * rank, per * rank + per))
+        assert [e is not None for e in moe.experts] == [i // per == rank for i in range(4)]
         ck_local, gate = fill(moe, seed=3)
         gate_t = torch.from_numpy(gate)
         dist.broadcast(gate_t, src=0)  # the router is replicated: every rank must hold rank 0's
@@ -129,12 +132,12 @@ def _worker(rank, world, port, q):
         raise
 
 
-def test_tp2_column_and_row_parallel_gloo():
-    world = 2
+@pytest.mark.parametrize("world,N", [(2, 192), (4, 4 * 1376)])
+def test_column_and_row_parallel_gloo(world, N):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]

@@ -57,6 +57,9 @@
 #ifndef W4A16_SLIM
 #define W4A16_SLIM 1    // streaming kernel: compact cross-wave reduction for up to 4 rows
 #endif
+#ifndef W4A16_WIDE_FROM
+#define W4A16_WIDE_FROM 20  // the 32x32x16 kernel serves single problems with more rows than this
+#endif
 #ifndef W4A16_ILV
 #define W4A16_ILV 1  // the 32x32x16 kernel deals matrix and conversion instructions out alternately
 #endif
@@ -866,7 +869,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int T, int KW, int SZS>
+template <int MT, int T, int KW, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_blocks, int panel_rows,
                                                             const GemmArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
@@ -902,15 +905,27 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   const int slice = (in_panel / rows_here) * 8 + xcd;
   const int mb = panel * panel_rows + in_panel % rows_here;
   if (slice >= n_slices) return;  // whole workgroup
-  const int ct0 = slice * T;      // first 32-column tile
+  // A 32-column tile of the matrix instruction is two 16-column tiles of the packed layout: normally neighbours.
+  // With the fused activation the weights are [gate | up] (N / 2 columns each, whole 16-column tiles) and tile
+  // j of the workgroup is made of gate columns 16 j .. 16 j + 15 and the SAME columns of the up half, so that a
+  // lane holds both operands of silu(gate) * up for its columns (accumulator registers 8 apart).
+  const int ct0 = slice * T;  // first tile
   const int m0 = mb * R;
+  auto tile16 = [&](int t) {
+    const int second = (lane >> 4) & 1;
+    if constexpr (ACT) {
+      const int nth = a.NT / 2;  // 16-column tiles per half
+      return min(ct0 + t, nth - 1) + second * nth;
+    }
+    // 16-column tiles past the end re-read the last one (valid memory); their results are dropped
+    return min(2 * (ct0 + t) + second, a.NT - 1);
+  };
 
   // Per-lane byte offsets from the (uniform) buffer bases: 32 bits each (the host checks the sizes).
   uint32_t woff[T], szoff[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    // 16-column tiles past the end re-read the last one (valid memory); their results are dropped
-    const int t16 = min(2 * (ct0 + t) + ((lane >> 4) & 1), a.NT - 1);
+    const int t16 = tile16(t);
     woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
     szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
   }
@@ -1138,14 +1153,34 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   }
   __syncthreads();
   STAMP(22);
-  for (int i = w; i < NSL; i += KW) {
+  auto total = [&](int i) {
     f32x4 v = red[i * 64 + lane];
 #pragma unroll
     for (int s = 1; s < LIVE; ++s) v += red[(s * NSL + i) * 64 + lane];
+    return v;
+  };
+  for (int io = w; io < (ACT ? NSL / 2 : NSL); io += KW) {
+    // fused activation: slices q = 0, 1 of a tile are gate columns, q = 2, 3 the same columns of the up half
+    const int i = ACT ? (io >> 1) * 4 + (io & 1) : io;
+    const f32x4 v = total(i);
     const int t = i / (MT * 4), mt = (i >> 2) % MT, q = i & 3;
-    const int n = (ct0 + t) * 32 + 8 * q + 4 * h;
     const int m = m0 + mt * 32 + r32;
-    if (m < a.M && n < a.N) {
+    if constexpr (ACT) {
+      // values are rounded to fp16 first, then the bias is added in fp16, then the activation: what the
+      // separate steps on an fp16 GEMM result give
+      const f32x4 vu = total(i + 2);
+      const int NH = a.N / 2;
+      const int n = (ct0 + t) * 16 + 8 * q + 4 * h;
+      if (m < a.M && n < NH) {
+        f16x4 hg = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        f16x4 hu = f16x4{(f16)vu.x, (f16)vu.y, (f16)vu.z, (f16)vu.w};
+        if (a.bias != nullptr) {
+          hg += *reinterpret_cast<const f16x4*>(a.bias + n);
+          hu += *reinterpret_cast<const f16x4*>(a.bias + NH + n);
+        }
+        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(hg, hu);
+      }
+    } else if (const int n = (ct0 + t) * 32 + 8 * q + 4 * h; m < a.M && n < a.N) {
       f16x4 hv = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
       if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + n);
       f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
@@ -1173,7 +1208,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 // instructions: with MT = 4 the conversion takes a quarter of the vector issue slots of the 16x16x32
 // kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
 // landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
-template <int MT, int T, int NW, int SZS>
+template <int MT, int T, int NW, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
                                                                    const GemmArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
@@ -1201,13 +1236,22 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   const int slice = (in_panel / rows_here) * 8 + xcd;
   const int mb = panel * panel_rows + in_panel % rows_here;
   if (slice >= n_slices) return;  // whole workgroup
-  const int ct0 = (slice * NW + w) * T;  // this wave's first 32-column tile
+  // fused activation: a tile is 16 gate columns and the same 16 columns of the up half (as in gemm_wide_kernel)
+  const int ct0 = (slice * NW + w) * T;  // this wave's first tile
   const int m0 = mb * R;
+  auto tile16 = [&](int t) {
+    const int second = (lane >> 4) & 1;
+    if constexpr (ACT) {
+      const int nth = a.NT / 2;
+      return min(ct0 + t, nth - 1) + second * nth;
+    }
+    return min(2 * (ct0 + t) + second, a.NT - 1);
+  };
 
   uint32_t woff[T], szoff[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const int t16 = min(2 * (ct0 + t) + ((lane >> 4) & 1), a.NT - 1);
+    const int t16 = tile16(t);
     woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
     szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
   }
@@ -1351,9 +1395,25 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nn = (ct0 + t) * 32 + 8 * q + 4 * h;
         const int m = m0 + mt * 32 + r32;
-        if (m < a.M && nn < a.N) {
+        if constexpr (ACT) {
+          // register groups 0, 1 are gate columns, 2, 3 the same columns of the up half; rounded to fp16,
+          // bias added in fp16, then the activation, as the separate steps would
+          const int NH = a.N / 2;
+          const int nn = (ct0 + t) * 16 + 8 * q + 4 * h;
+          if (q < 2 && m < a.M && nn < NH) {
+            constexpr int up = ACT ? 8 : 0;
+            f16x4 hg = f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2],
+                             (f16)acc[t][mt][4 * q + 3]};
+            f16x4 hu = f16x4{(f16)acc[t][mt][(4 * q + up) & 15], (f16)acc[t][mt][(4 * q + 1 + up) & 15],
+                             (f16)acc[t][mt][(4 * q + 2 + up) & 15], (f16)acc[t][mt][(4 * q + 3 + up) & 15]};
+            if (a.bias != nullptr) {
+              hg += *reinterpret_cast<const f16x4*>(a.bias + nn);
+              hu += *reinterpret_cast<const f16x4*>(a.bias + NH + nn);
+            }
+            *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + nn) = silu_mul(hg, hu);
+          }
+        } else if (const int nn = (ct0 + t) * 32 + 8 * q + 4 * h; m < a.M && nn < a.N) {
           f16x4 hv = f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2],
                            (f16)acc[t][mt][4 * q + 3]};
           if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + nn);
@@ -1440,9 +1500,8 @@ __global__ void __launch_bounds__(KW * 64) gemm_stock_kernel(const f16* __restri
       }
     }
     // 8 x 8 nibble transpose: swap the off-diagonal blocks of size 4, 2, 1
-#pragma unroll
-    for (int b = 4; b >= 1; b >>= 1) {
-      const uint32_t mask = b == 4 ? 0x0000ffffu : b == 2 ? 0x00ff00ffu : 0x0f0f0f0fu;
+    auto swap_blocks = [&](auto b_, uint32_t mask) {
+      constexpr int b = decltype(b_)::value;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i & b) continue;
@@ -1450,7 +1509,10 @@ __global__ void __launch_bounds__(KW * 64) gemm_stock_kernel(const f16* __restri
         r[i + b] ^= t;
         r[i] ^= t << (4 * b);
       }
-    }
+    };
+    swap_blocks(Flag<4>{}, 0x0000ffffu);
+    swap_blocks(Flag<2>{}, 0x00ff00ffu);
+    swap_blocks(Flag<1>{}, 0x0f0f0f0fu);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const f16x8 af = dequant_word(r[j], sz[j], dqc);
@@ -1824,18 +1886,27 @@ int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t
 }
 
 template <int MT, int T, int KW>
-int launch_wide(const GemmArgs& a, hipStream_t s, int batch) {
+int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   constexpr int stage = KW * MT * 32 * 256;  // one private slab per wave
   constexpr int reduce = (KW > 4 ? KW / 2 : KW) * T * MT * 4 * 1024;     // partial tiles
   constexpr int lds = stage > reduce ? stage : reduce;
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks only, and 32-bit byte offsets into the three buffers
   if (a.K % 128 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31)) return W4A16_E_SHAPE;
+  // fused activation: a tile is 16 gate + 16 up columns, so there are N / 32 of them too
+  if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T);
   const int m_blocks = ceil_div(a.M, MT * 32);
   const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
-  if (a.G % 128 == 0)
+  if (act) {
+    if (a.G % 128 == 0)
+      kern = gemm_wide_kernel<MT, T, KW, 4, true>;
+    else if (a.G == 64)
+      kern = gemm_wide_kernel<MT, T, KW, 2, true>;
+    else
+      kern = gemm_wide_kernel<MT, T, KW, 1, true>;
+  } else if (a.G % 128 == 0)
     kern = gemm_wide_kernel<MT, T, KW, 4>;
   else if (a.G == 64)
     kern = gemm_wide_kernel<MT, T, KW, 2>;
@@ -1858,26 +1929,34 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch) {
 #define W4A16_FOR_EACH_WIDE(X) \
   X(2, 3, 8) X(2, 2, 8) X(2, 1, 8) X(1, 3, 8) X(1, 2, 8) X(2, 3, 4) X(2, 2, 4) X(1, 3, 4)
 
-int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch = 1) {
+int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch = 1, bool act = false) {
 #define X(MT_, T_, KW_) \
-  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch);
+  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch, act);
   W4A16_FOR_EACH_WIDE(X)
 #undef X
   return W4A16_E_SHAPE;
 }
 
 template <int MT, int T, int NW>
-int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch) {
+int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   constexpr int lds = 3 * MT * 32 * 256;  // ring of three slabs
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks, at least two of them, and 32-bit byte offsets into the three buffers
   if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
     return W4A16_E_SHAPE;
+  if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T * NW);
   const int m_blocks = ceil_div(a.M, MT * 32);
   const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
-  if (a.G % 128 == 0)
+  if (act) {
+    if (a.G % 128 == 0)
+      kern = gemm_wide_shared_kernel<MT, T, NW, 4, true>;
+    else if (a.G == 64)
+      kern = gemm_wide_shared_kernel<MT, T, NW, 2, true>;
+    else
+      kern = gemm_wide_shared_kernel<MT, T, NW, 1, true>;
+  } else if (a.G % 128 == 0)
     kern = gemm_wide_shared_kernel<MT, T, NW, 4>;
   else if (a.G == 64)
     kern = gemm_wide_shared_kernel<MT, T, NW, 2>;
@@ -1899,9 +1978,9 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch) {
 // (mt, t, nw) of the shared-slab 32x32x16 kernel
 #define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(4, 2, 4) X(4, 1, 4) X(2, 1, 8) X(2, 2, 8) X(2, 2, 4) X(2, 3, 8)
 
-int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1) {
+int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1, bool act = false) {
 #define X(MT_, T_, NW_) \
-  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch);
+  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch, act);
   W4A16_FOR_EACH_WIDE_SHARED(X)
 #undef X
   return W4A16_E_SHAPE;
@@ -1988,7 +2067,7 @@ Choice choose_wide(int M, int K, int N, int batch) {
 Choice choose_wide_shared(int M, int K, int N, int batch) {
   static const int cand[][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}, {2, 3}};
   static const double rate[] = {1.0, 1.048, 0.854, 0.905, 0.914};
-  Choice best{true, 4, 1, 1, -8};
+  Choice best{true, 4, 1, 8, -1};
   double best_cost = 1e300;
   for (int i = 0; i < 5; ++i) {
     const int mt = cand[i][0], t = cand[i][1];
@@ -2001,15 +2080,24 @@ Choice choose_wide_shared(int M, int K, int N, int batch) {
 
 Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
-  // 33-256 rows: the 32x32x16 kernel, 10-40 % faster than the 16x16x32 kernels on every layer shape measured
-  // (whole 128-k blocks and 32-bit byte offsets only; no fused activation)
-  if (!act && M > 32 && M <= 256 && K % 128 == 0 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
-      (long long)M * K < (1LL << 31))
+  // The 32x32x16 kernels read whole 128-k blocks through 32-bit byte offsets.  (With the fused activation a
+  // tile is 16 gate + 16 up columns: as many tiles, and the same launch shapes, as the plain GEMM on N columns.)
+  const bool wide_ok = K % 128 == 0 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
+                       (long long)M * K < (1LL << 31);
+  // 33-256 rows: 10-40 % faster than the 16x16x32 kernels on every layer shape measured
+  if (wide_ok && M > 32 && M <= 256) return choose_wide(M, K, N, batch);
+  // 21-32 rows of a single problem: its one-row-tile shapes beat the 16x16x32 kernels by 5-25 % from K = 2048 up
+  // (at 24 / 32 rows, 4096 x 11008: 10.2 / 10.6 against 11.6 / 11.6 us; 4096 x 4096: 7.8 / 7.9 against 9.5 / 9.8;
+  // 4096 x 14336: 11.0 / 11.4 against 14.6 / 14.8; 8192 x 1280: 12.0 against 15.4; 4096 x 1376: 7.7 / 7.8 against
+  // 9.2 / 10.6); with at most 128 column tiles (4096 columns) twice as many workgroups of one tile each do better
+  // still (11008 x 4096: 19.0 / 20.0 against 20.4 / 20.5).  At 17 rows the streaming kernel, whose cost grows with
+  // the rows, is still ahead on narrow layers and long K (11008 x 4096: 16.4 against 18.9), and at K = 1024 always.
+  if (wide_ok && batch == 1 && M > W4A16_WIDE_FROM && M <= 32 && K >= 2048) {
+    if (ceil_div(N, 32) <= 128) return Choice{true, 2, 1, 1, -8};
     return choose_wide(M, K, N, batch);
+  }
   // more rows: one activation slab shared by the workgroup's eight waves, wide tiles
-  if (!act && M > 256 && K % 128 == 0 && K >= 256 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
-      (long long)M * K < (1LL << 31))
-    return choose_wide_shared(M, K, N, batch);
+  if (wide_ok && M > 256 && K >= 256) return choose_wide_shared(M, K, N, batch);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
   // 24-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
@@ -2320,8 +2408,7 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
     mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
   }
   if (b_ < 0) {  // 32x32x16 kernels: (mt, t, 1, -kw) private slabs, (mt, t, nw > 1, any b < 0) shared slab
-    if (act) return W4A16_E_SHAPE;
-    return a_ > 1 ? dispatch_wide_shared(a, mt, t, a_, s, batch) : dispatch_wide(a, mt, t, -b_, s, batch);
+    return a_ > 1 ? dispatch_wide_shared(a, mt, t, a_, s, batch, act) : dispatch_wide(a, mt, t, -b_, s, batch, act);
   }
   if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
   return dispatch_packed(a, mt, t, a_, s, batch, act);
