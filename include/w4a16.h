@@ -231,6 +231,14 @@ enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFM
 int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5]);
 
 /*
+ * Enumerates the launch shapes this build holds of kernel `kernel` (W4A16_KERNEL_*): shape number `index`
+ * (0, 1, ..) in the order of the arguments the _cfg entry points take - STREAMING (mt, t, waves),
+ * LDS_STAGED (mt, t, nw, kw), MFMA32 (mt, t, kw), MFMA32_SHARED (mt, t, nw); W4A16_E_SHAPE past the last one.
+ * Lets a test suite run every shape that exists instead of a list kept by hand.  No counterpart in the reference.
+ */
+int w4a16_built_shape(int kernel, int index, int shape[4]);
+
+/*
  * Measurement aid: one pass of 16-byte non-temporal loads over `bytes` bytes at `src` (16-byte aligned),
  * nothing else; `sink` is a device buffer of at least 8 KiB that is (practically) never written.  Its
  * duration on a buffer of a layer's packed size is the floor for that layer's decode launch on the same

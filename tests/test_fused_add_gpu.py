@@ -42,7 +42,8 @@ CASES = [  # M, K, N, G, bias?, launch shapes to force (None = the library's cho
     (5, 384, 440, 128, True, [None, (1, 6, 8, 0), (1, 4, 4, 0)]),
     (20, 256, 200, 64, False, [None, (2, 1, 16, 0), (2, 4, 8, 0)]),
     (33, 11008, 96, 128, True, [None, (2, 3, 1, 8)]),
-    (70, 640, 416, 32, True, [None, (4, 3, 2, 4), (4, 3, 4, 2), (2, 3, 2, 4), (4, 3, 8, 0)]),
+    (70, 640, 416, 32, True, [None, (4, 3, 2, 4), (4, 3, 4, 2), (2, 3, 2, 4), (2, 3, 8, 0), (2, 3, 1, -8), (1, 2, 1, -8),
+                              (2, 2, 1, -4), (4, 1, 8, -1), (2, 3, 8, -1)]),
     (130, 1024, 1376, 128, False, [None]),
     (300, 512, 512, 128, False, [None]),
 ]

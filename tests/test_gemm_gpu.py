@@ -170,33 +170,41 @@ def test_ragged_m(abi, cuda, M):
     assert_parity(abi.gemm_stock(tx, tqw, ts, tqz).cpu().numpy(), want, exact, strict=True, what=f"stock M={M}")
 
 
-CFGS = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 8), (1, 6, 8), (1, 1, 8), (1, 3, 8), (1, 8, 8), (1, 1, 4),
-        (1, 4, 4), (2, 1, 16), (2, 4, 8), (2, 3, 8), (2, 6, 8), (2, 3, 4), (4, 1, 8), (4, 3, 8), (4, 6, 8),
-        (4, 3, 4), (8, 1, 8), (8, 3, 8), (8, 1, 4), (8, 3, 4),
-        # LDS-staged kernel: (mt, t, nw, kw)
-        (4, 3, 2, 4), (4, 3, 4, 2), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (2, 3, 2, 4), (2, 3, 1, 4),
-        (8, 3, 2, 2), (8, 3, 1, 2), (4, 6, 1, 4), (2, 6, 1, 4),
-        # 32x32x16 kernel: ("wide", mt, t, kw)
-        ("wide", 2, 3, 8), ("wide", 2, 2, 8), ("wide", 2, 1, 8), ("wide", 1, 3, 8), ("wide", 1, 2, 8),
-        ("wide", 2, 3, 4), ("wide", 2, 2, 4), ("wide", 1, 3, 4),
-        # shared-slab 32x32x16 kernel: ("wide", mt, t, -nw)
-        ("wide", 4, 1, -8), ("wide", 4, 2, -4), ("wide", 4, 1, -4), ("wide", 2, 1, -8), ("wide", 2, 2, -8),
-        ("wide", 2, 2, -4)]
+def all_built_shapes(L):
+    """Every launch shape the library holds, in the form CABI.gemm_packed takes: streaming (mt, t, waves),
+    LDS-staged (mt, t, nw, kw), 32x32x16 ("wide", mt, t, kw), shared-slab 32x32x16 ("wide", mt, t, -nw)."""
+    cfgs = list(L.built_shapes(0)) + list(L.built_shapes(1))
+    cfgs += [("wide", ) + c for c in L.built_shapes(2)]
+    cfgs += [("wide", mt, t, -nw) for mt, t, nw in L.built_shapes(3)]
+    return cfgs
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
-def test_every_launch_shape(abi, cuda, G):
-    M, K, N = 85, 1280, 400  # 6 row tiles (ragged), 10 k-blocks, 25 column tiles (ragged against every T)
-    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=G)
-    want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
-    tx, tqw, ts, tqz = [dev_t(a, cuda) for a in (x, qw, s, qz)]
-    packed = abi.repack(tqw, ts, tqz)
-    for cfg in CFGS:
-        y = abi.gemm_packed(tx, packed, cfg=cfg)
-        assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"G={G} cfg={cfg}")
-    for m in (3, 20, M):  # the three launch shapes of the stock-layout kernel at this group size
-        assert_parity(abi.gemm_stock(tx[:m].contiguous(), tqw, ts, tqz).cpu().numpy(), want[:m], exact[:m],
-                      strict=True, what=f"G={G} stock M={m}")
+def test_every_launch_shape(abi, L, cuda, G):
+    CFGS = all_built_shapes(L)
+    assert len(CFGS) == 22 + 7 + 8 + 5  # a shape added to the library is a shape tested here
+    # 6 row tiles (ragged), 25 column tiles (ragged against every T); 10 k-blocks (uneven over 4 or 8 K-groups),
+    # and 16 for the LDS-staged shapes with 8 K-groups, which take whole rounds of 8 blocks only
+    M, N = 85, 400
+    for K in (1280, 2048):
+        x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=G + K)
+        want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
+        tx, tqw, ts, tqz = [dev_t(a, cuda) for a in (x, qw, s, qz)]
+        packed = abi.repack(tqw, ts, tqz)
+        for cfg in CFGS:
+            staged8 = len(cfg) == 4 and cfg[0] != "wide" and cfg[3] == 8
+            if K == 1280 and staged8:
+                with pytest.raises(ValueError):
+                    abi.gemm_packed(tx, packed, cfg=cfg)
+                continue
+            if K == 2048 and not staged8 and cfg[0] != "wide":
+                continue  # covered at 10 blocks
+            y = abi.gemm_packed(tx, packed, cfg=cfg)
+            assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"G={G} K={K} cfg={cfg}")
+        if K == 1280:
+            for m in (3, 20, M):  # the three launch shapes of the stock-layout kernel at this group size
+                assert_parity(abi.gemm_stock(tx[:m].contiguous(), tqw, ts, tqz).cpu().numpy(), want[:m], exact[:m],
+                              strict=True, what=f"G={G} stock M={m}")
 
 
 @pytest.mark.parametrize("K,N,G", [(96, 40, 32), (160, 8, 32), (32, 16, 32), (224, 72, 32), (4096 + 128, 64, 128)])
@@ -274,7 +282,7 @@ def test_default_launch_shape_branches_parity(abi, cuda, K, N, M):
     assert_parity_slack(y, *reference_arithmetic(x, orc.dequantize(qw, s, qz)), what=f"{K}x{N} M={M}")
 
 
-@pytest.mark.parametrize("cfg", [("wide", 2, 3, 8), ("wide", 1, 3, 8), ("wide", 2, 2, 4), ("wide", 4, 1, -8), ("wide", 2, 2, -4)])
+@pytest.mark.parametrize("cfg", [("wide", 2, 3, 8), ("wide", 1, 3, 8), ("wide", 2, 2, 4), ("wide", 4, 1, -8), ("wide", 2, 2, -8)])
 def test_full_size_wide_kernel(abi, cuda, full, cfg):
     """The 32x32x16 kernel at 4096 x 11008: oracle parity at 100 (ragged) rows, and unit rows x = e_k,
     which must return rows of the dequantised weights bit for bit (the whole k <-> lane <-> word mapping

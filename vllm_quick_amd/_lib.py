@@ -45,6 +45,7 @@ SYMBOLS = {
                                      [c_int] * 6 + [c_void_p, c_int, c_void_p]),
     "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "w4a16_launch_shape": (c_int, [c_int] * 5 + [ctypes.POINTER(c_int)]),
+    "w4a16_built_shape": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "w4a16_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
 }
 
@@ -83,6 +84,14 @@ def launch_shape(M: int, K: int, N: int, batch: int = 1, epilogue: int = 0) -> s
     kind, mt, t, a, b = list(buf)
     args = {0: (mt, t, a), 1: (mt, t, a, b), 2: (mt, t, b), 3: (mt, t, a)}[kind]
     return f"{KERNEL_NAMES[kind]}<{','.join(str(v) for v in args)}>"
+
+
+def built_shapes(kernel: int):
+    """Every launch shape of one kernel this build holds, as tuples of the _cfg entry points' arguments."""
+    out, buf = [], (c_int * 4)()
+    while lib.w4a16_built_shape(kernel, len(out), buf) == 0:
+        out.append(tuple(buf)[:4 if kernel == 1 else 3])
+    return out
 
 
 def check(code: int, what: str) -> None:

@@ -1872,9 +1872,10 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
 }
 
 // (mt, t, nw, kw) of the LDS-staged kernel
+// (the shapes choose_cfg can return; the kernel serves what the 32x32x16 kernels do not take: K not a
+// multiple of 128, 24-32 rows of short-K or batched problems)
 #define W4A16_FOR_EACH_TILED(X) \
-  X(4, 2, 3, 4) X(4, 3, 2, 4) X(4, 3, 1, 4) X(4, 2, 2, 4) X(4, 3, 2, 2) X(4, 3, 4, 2) X(2, 3, 2, 4) X(2, 3, 1, 4) X(8, 3, 1, 2) \
-  X(8, 3, 2, 2) X(4, 6, 1, 4) X(2, 6, 1, 4) X(1, 3, 1, 8) X(1, 1, 3, 4) X(1, 3, 1, 4) X(2, 3, 1, 8)
+  X(4, 3, 2, 4) X(4, 3, 4, 2) X(4, 3, 1, 4) X(4, 2, 2, 4) X(2, 3, 2, 4) X(2, 3, 1, 4) X(2, 3, 1, 8)
 
 int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1,
                    bool act = false) {
@@ -1976,7 +1977,7 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
 }
 
 // (mt, t, nw) of the shared-slab 32x32x16 kernel
-#define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(4, 2, 4) X(4, 1, 4) X(2, 1, 8) X(2, 2, 8) X(2, 2, 4) X(2, 3, 8)
+#define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(2, 1, 8) X(2, 2, 8) X(2, 3, 8)
 
 int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1, bool act = false) {
 #define X(MT_, T_, NW_) \
@@ -1986,19 +1987,15 @@ int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s
   return W4A16_E_SHAPE;
 }
 
-// (mt, t, waves) -> instantiation.  mt in {1,2,4,8}; t in 1..8 with mt*t <= 24;
-// waves 16 for mt <= 2 (128 VGPRs/lane are enough), 8 for mt >= 4; plus 4/8 for short K.
+// (mt, t, waves) -> instantiation.  One or two 16-row tiles (more rows go to the other kernels); t in 1..8;
+// 16 waves where 128 VGPRs per lane are enough, 4 / 8 for short K and for small workgroups, several to a CU.
 #define W4A16_FOR_EACH_CFG(X) \
   X(1, 1, 16) X(1, 2, 16) X(1, 3, 16)                                     \
   X(1, 1, 8)  X(1, 2, 8)  X(1, 3, 8)  X(1, 4, 8)  X(1, 6, 8)  X(1, 8, 8)  \
   X(1, 1, 4)  X(1, 2, 4)  X(1, 3, 4)  X(1, 4, 4)                          \
   X(2, 1, 16)                                                             \
   X(2, 1, 8)  X(2, 2, 8)  X(2, 3, 8)  X(2, 4, 8)  X(2, 6, 8)              \
-  X(2, 1, 4)  X(2, 2, 4)  X(2, 3, 4)                                      \
-  X(4, 1, 8)  X(4, 2, 8)  X(4, 3, 8)  X(4, 4, 8)  X(4, 6, 8)              \
-  X(4, 1, 4)  X(4, 2, 4)  X(4, 3, 4)                                      \
-  X(8, 1, 8)  X(8, 2, 8)  X(8, 3, 8)                                      \
-  X(8, 1, 4)  X(8, 2, 4)  X(8, 3, 4)
+  X(2, 1, 4)  X(2, 2, 4)  X(2, 3, 4)
 
 int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1,
                     bool act = false) {
@@ -2464,6 +2461,27 @@ int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5
     shape[0] = W4A16_KERNEL_MFMA32, shape[3] = 1, shape[4] = -c.b;
   }
   return W4A16_OK;
+}
+
+int w4a16_built_shape(int kernel, int index, int shape[4]) {
+  if (!shape) return W4A16_E_NULL;
+  if (index < 0) return W4A16_E_SHAPE;
+  int i = 0;
+  shape[0] = shape[1] = shape[2] = shape[3] = 0;
+#define X3(A_, B_, C_) \
+  if (i++ == index) return shape[0] = A_, shape[1] = B_, shape[2] = C_, W4A16_OK;
+#define X4(A_, B_, C_, D_) \
+  if (i++ == index) return shape[0] = A_, shape[1] = B_, shape[2] = C_, shape[3] = D_, W4A16_OK;
+  switch (kernel) {
+    case W4A16_KERNEL_STREAMING: W4A16_FOR_EACH_CFG(X3) break;
+    case W4A16_KERNEL_LDS_STAGED: W4A16_FOR_EACH_TILED(X4) break;
+    case W4A16_KERNEL_MFMA32: W4A16_FOR_EACH_WIDE(X3) break;
+    case W4A16_KERNEL_MFMA32_SHARED: W4A16_FOR_EACH_WIDE_SHARED(X3) break;
+    default: break;
+  }
+#undef X3
+#undef X4
+  return W4A16_E_SHAPE;
 }
 
 int w4a16_stream_read(const void* src, size_t bytes, void* sink, void* stream) {

@@ -164,11 +164,9 @@ class MixtralMoE(torch.nn.Module):
             # the reference's loop (mixtral_quant.py:145-157), with the sum over experts kept in fp32 and
             # rounded once like the batched route below, so that one module gives the same values whichever
             # route a call takes (the reference adds the fp16 products one by one)
-            acc = None
-            for j, idx in enumerate(self.expert_indicies):
-                cur = self.experts[idx](hidden_states).mul_(expert_weights[:, j:j + 1])
-                acc = cur.float() if acc is None else acc.add_(cur)
-            final = acc.to(hidden_states.dtype)
+            scaled = [self.experts[idx](hidden_states).mul_(expert_weights[:, j:j + 1])
+                      for j, idx in enumerate(self.expert_indicies)]
+            final = torch.stack(scaled).sum(0, dtype=torch.float32).to(hidden_states.dtype)
         else:
             b13, b2 = batches
             E = len(self.expert_indicies)
