@@ -14,6 +14,8 @@ import glob
 import json
 import os
 import re
+import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,8 +24,28 @@ out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
 
+def demangle(name):
+    if not name.startswith("_Z"):
+        return name
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip()
+        except (OSError, subprocess.CalledProcessError):
+            continue
+        if out and out != name:
+            return out
+    return name
+
+
 def short(name):
-    m = re.search(r"(gemm_\w+_kernel<[^>]*>|dequant_\w+_kernel|repack_\w+_kernel)", name)
+    name = demangle(name)
+    m = re.match(r"_ZN\d+_GLOBAL__N_1\d+(\w+?_kernel)I((?:Li\d+E)+)E", name)  # no demangler knew the _Float16 mangling
+    if m:
+        return m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    m = re.search(r"(gemm_\w+_kernel<[^>]*>|dequant_\w+_kernel|repack_\w+_kernel|stream_read_kernel)", name)
     if m:
         return m.group(1)
     name = re.sub(r"\(.*", "", name)
@@ -78,8 +100,6 @@ for key, m in (("m128", 128), ("m1", 1)):
         if k.replace(" ", "").startswith(want[:-1] + ","):
             traffic[f"{key}_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
             traffic[f"{key}_kernel"] = want
-import subprocess  # noqa: E402
-
 traffic["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
                                    text=True).stdout.strip()
 traffic["dirty"] = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "vllm_quick_amd/csrc"],
@@ -88,4 +108,7 @@ traffic["source"] = f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / 
 for name in (f"{tag}_traffic.json", "traffic.json"):
     with open(os.path.join(out_dir, name), "w") as f:
         json.dump(traffic, f, indent=1)
+for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json")):
+    if os.path.exists(os.path.join(ROOT, "gpurun_out", src)):
+        shutil.copyfile(os.path.join(ROOT, "gpurun_out", src), os.path.join(out_dir, dst))
 print(json.dumps(traffic, indent=1))
