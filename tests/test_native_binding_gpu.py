@@ -103,3 +103,34 @@ def test_graph_capture_and_replay(native, cuda):
     torch.cuda.synchronize()
     assert native.stock_kernel_calls() == before + 1
     assert torch.allclose(y3.float(), native.ops.awq_gemm(static_x, qw3, s3, qz3, 8).float(), rtol=1e-2, atol=1e-3)
+
+
+def test_python_binding_counts_and_warns_when_the_stock_kernel_serves(ops, cuda):
+    """The ctypes mirror of the two operators behaves like the compiled one: warmed-up layers replay from a
+    graph on the packed kernels; a layer first seen under capture is served by the stock-layout kernel,
+    which is counted and warned about (once per process)."""
+    import warnings
+    x, qw, s, qz = [dev_t(a, cuda) for a in orc.make_inputs(8, 512, 256, 128, seed=14)]
+    eager = ops.awq_gemm(x, qw, s, qz, 8)  # warm-up
+    torch.cuda.synchronize()
+    before = ops.stock_kernel_calls()
+    stream = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream), torch.cuda.graph(g, stream=stream):
+        y = ops.awq_gemm(x, qw, s, qz, 8)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, eager) and ops.stock_kernel_calls() == before
+    x2, qw2, s2, qz2 = [dev_t(a, cuda) for a in orc.make_inputs(8, 512, 256, 128, seed=15)]
+    g2 = torch.cuda.CUDAGraph()
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        with torch.cuda.stream(stream), torch.cuda.graph(g2, stream=stream):
+            y2 = ops.awq_gemm(x2, qw2, s2, qz2, 8)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert ops.stock_kernel_calls() == before + 1
+    if before == 0:
+        assert any("stock-layout kernel" in str(w.message) for w in seen)
+    want = orc.gemm_faithful(*[t.cpu().numpy() for t in (x2, qw2, s2, qz2)])
+    assert np.allclose(y2.float().cpu().numpy(), want.astype(np.float32), rtol=1e-2, atol=1e-3)

@@ -14,6 +14,7 @@ repacked by an earlier (warm-up) call.
 """
 from __future__ import annotations
 
+import warnings
 import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Tuple
@@ -464,8 +465,25 @@ def awq_gemm(_in_feats: torch.Tensor, _kernel: torch.Tensor, _scaling_factors: t
     if _kernel.is_contiguous() and _scaling_factors.is_contiguous() and _zeros.is_contiguous():
         packed = _cached_pack(_kernel, _scaling_factors, _zeros)
     if packed is None:
+        # No packed copy can be made now (non-contiguous tensors, or the stream is being captured and this
+        # layer was never called before): the stock-layout kernel serves the call, three to five times slower,
+        # and if this is a capture the graph keeps it.  Counted, and said once.
+        global _stock_calls
+        _stock_calls += 1
+        if _stock_calls == 1:
+            warnings.warn("awq_gemm: a call was served by the stock-layout kernel (first call on these weights "
+                          "while a HIP graph is being captured, or non-contiguous weights); run one eager call per "
+                          "layer before capturing to get the packed-layout kernels", RuntimeWarning, stacklevel=2)
         return awq_gemm_stock(_in_feats, _kernel, _scaling_factors, _zeros)
     return awq_gemm_packed(_in_feats, packed)
+
+
+_stock_calls = 0
+
+
+def stock_kernel_calls() -> int:
+    """How many awq_gemm calls the stock-layout kernel has served in this process."""
+    return _stock_calls
 
 
 def awq_dequantize(_kernel: torch.Tensor, _scaling_factors: torch.Tensor, _zeros: torch.Tensor, split_k_iters: int,

@@ -14,7 +14,7 @@
 // only for the very same tensors at the same version counters, so in-place weight loading, freed and
 // re-used addresses and fresh views all miss and re-pack.  Nothing is re-ordered or allocated for the
 // table while the current stream is capturing a graph: such a call is served by the shape-agnostic
-// kernel on the stock layout (about ten times slower), counted in stock_kernel_calls() and warned about
+// kernel on the stock layout (three to five times slower), counted in stock_kernel_calls() and warned about
 // once - run one eager warm-up call per layer before capturing, as vLLM does
 // (vllm/worker/model_runner.py:765-775).
 #include <ATen/hip/HIPContext.h>
