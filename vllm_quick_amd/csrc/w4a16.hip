@@ -547,6 +547,28 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
 
 // ---------------------------------------------------------------------------
 // GEMM on the private layout, activations staged through LDS (M > 32)
+
+// Workgroup id -> (column slice, row block) for the kernels whose workgroups own a [rows] x [columns] tile.
+// The work items are listed panel by panel (a panel = `panel_rows` row blocks: all of them up to 8, else a few),
+// within a panel slice by slice with the panel's row blocks of a slice next to each other.  Workgroup ids
+// congruent to x mod 8 run on XCD x, which takes the x-th eighth of that list in order: the workgroups an XCD
+// runs at a time then share their weight slices AND their activation rows through its L2, and every XCD gets
+// the same number of items whatever the slice count is (slices dealt out modulo 8 left up to a whole slice's
+// row blocks more on some XCDs: 36 workgroups against 24 on 32 CUs in bad cases).
+__device__ __forceinline__ bool map_workgroup(int n_slices, int m_blocks, int panel_rows, int& slice, int& mb) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int total = n_slices * m_blocks;
+  const int per = (total + 7) >> 3;
+  const int j = xcd * per + idx;
+  if (j >= total) return false;
+  const int per_panel = panel_rows * n_slices;
+  const int panel = j / per_panel, in_panel = j - panel * per_panel;
+  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
+  slice = in_panel / rows_here;
+  mb = panel * panel_rows + in_panel % rows_here;
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // A workgroup owns MT x (NW * T) output tiles over the whole of K.  Its NW * KW waves form
 // KW K-groups (group kg takes 128-k blocks kg, kg + KW, ...) of NW waves that split the
@@ -596,13 +618,8 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
   // slice, and for each slice the panel's row-blocks next to each other, so that the ~32 workgroups
   // an XCD runs at a time share their weight slices AND their activation rows through its L2.
   // Up to 8 row-blocks the panel is all of them: the row-blocks of a slice get ids 8 apart.
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
-  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
-  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
-  const int slice = (in_panel / rows_here) * 8 + xcd;
-  const int mb = panel * panel_rows + in_panel % rows_here;
-  if (slice >= n_slices) return;  // whole workgroup: no barrier is skipped by a subset
+  int slice, mb;
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
   const int nt0 = (slice * HW + nw % HW) * T;
   const int m0 = mb * ROWS;
 
@@ -898,13 +915,8 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 
   // workgroup id -> (column slice, row block): row blocks of a slice share an XCD (ids 8 apart), in
   // panels once there are more than 8 of them (as gemm_tiled_kernel)
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
-  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
-  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
-  const int slice = (in_panel / rows_here) * 8 + xcd;
-  const int mb = panel * panel_rows + in_panel % rows_here;
-  if (slice >= n_slices) return;  // whole workgroup
+  int slice, mb;
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
   // A 32-column tile of the matrix instruction is two 16-column tiles of the packed layout: normally neighbours.
   // With the fused activation the weights are [gate | up] (N / 2 columns each, whole 16-column tiles) and tile
   // j of the workgroup is made of gate columns 16 j .. 16 j + 15 and the SAME columns of the up half, so that a
@@ -1229,13 +1241,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, h = lane >> 5;
 
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int per_panel = panel_rows * ((n_slices + 7) >> 3);
-  const int panel = idx / per_panel, in_panel = idx - panel * per_panel;
-  const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
-  const int slice = (in_panel / rows_here) * 8 + xcd;
-  const int mb = panel * panel_rows + in_panel % rows_here;
-  if (slice >= n_slices) return;  // whole workgroup
+  int slice, mb;
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
   // fused activation: a tile is 16 gate columns and the same 16 columns of the up half (as in gemm_wide_kernel)
   const int ct0 = (slice * NW + w) * T;  // this wave's first tile
   const int m0 = mb * R;
@@ -1838,7 +1845,7 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   if (a.KBS % KW) return W4A16_E_SHAPE;
   const int n_slices = act ? ceil_div(a.NT / 2, NW / 2 * T) : ceil_div(a.NT, NW * T);
   const int m_blocks = ceil_div(a.M, MT * 16);
-  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
   if (act) {
     if constexpr (kActTiled<MT, T, NW, KW>) {
@@ -1898,7 +1905,7 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T);
   const int m_blocks = ceil_div(a.M, MT * 32);
-  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
   if (act) {
     if (a.G % 128 == 0)
@@ -1948,7 +1955,7 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T * NW);
   const int m_blocks = ceil_div(a.M, MT * 32);
-  const int blocks = ceil_div(n_slices, 8) * 8 * m_blocks;
+  const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
   if (act) {
     if (a.G % 128 == 0)
@@ -1977,7 +1984,7 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
 }
 
 // (mt, t, nw) of the shared-slab 32x32x16 kernel
-#define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(2, 1, 8) X(2, 2, 8) X(2, 3, 8)
+#define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(2, 1, 8) X(2, 2, 8) X(2, 3, 8) X(4, 3, 4) X(4, 2, 4)
 
 int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1, bool act = false) {
 #define X(MT_, T_, NW_) \
@@ -2025,52 +2032,35 @@ struct Choice {
   int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
 };
 
-// Launch shape of the 32x32x16 kernel (gemm_wide_kernel) for 33-256 rows: the candidate with the lowest
-// estimated time.  A workgroup's time is the larger of its arithmetic (matrix instructions at 32 cycles
-// each over 4 SIMDs; the int4 -> fp16 conversion, 13 vector instructions per weight word, overlaps them
-// when a SIMD has two waves to alternate between and adds to them when it has one) and of the bytes it pulls
-// through the CU's vector memory path, plus a fixed cost for prologue, cross-wave reduction and stores;
-// the busiest CU runs ceil(workgroups / 256) of them.  The five constants were fitted on all built shapes
-// x 11 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral) x 48-256 rows
-// (scripts/exp_wide.py): mean loss against the best built shape 0.4 %, worst 6 %.
-Choice choose_wide(int M, int K, int N, int batch) {
-  static const int cand[][3] = {{2, 3, 8}, {2, 2, 8}, {2, 1, 8}, {1, 3, 8}, {1, 2, 8}, {2, 3, 4}, {2, 2, 4}, {1, 3, 4}};
-  const double KB = K / 128;
-  Choice best{true, 2, 3, 1, -8};
+// Launch shape of the two 32x32x16 kernels: the built shape with the lowest estimated time,
+//   ceil(workgroups / 256 CUs) x (K / 128 x a + b)   microseconds,
+// a (per 128-k block) and b (prologue, reduction, stores) per shape, fitted by least squares on all fifteen
+// shapes x 14 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral, 2/4/8-way shards of the
+// benchmark layer) x 24-4096 rows (scripts/exp_shared_sweep.py): mean loss against the best built shape 0.6 %,
+// worst 12 %; with each layer shape held out of the fit in turn, 0.5 % and 12 %.  The private-slab kernel splits K
+// over the waves of a workgroup, so it keeps many workgroups on narrow layers at any row count (8192 x 1280 at
+// 512 rows: 20 us against 58 for the best shared-slab shape); the shared-slab kernel wins where rows x columns
+// alone fill the chip.
+Choice choose_mfma32(int M, int K, int N, int batch) {
+  struct Shape {
+    int mt, t, nw, kw;  // private slabs: nw = 1; shared slab: kw = 1
+    double a, b;
+  };
+  static const Shape shapes[] = {
+      {1, 2, 1, 8, 0.1707, 1.339}, {1, 3, 1, 4, 0.2491, 1.322}, {1, 3, 1, 8, 0.2275, 2.981}, {2, 1, 1, 8, 0.1879, 2.008},
+      {2, 2, 1, 4, 0.2536, 2.083}, {2, 2, 1, 8, 0.2408, 3.344}, {2, 3, 1, 4, 0.3149, 3.871}, {2, 3, 1, 8, 0.2981, 4.660},
+      {2, 1, 8, 1, 0.8765, 3.995}, {2, 2, 8, 1, 1.4621, 6.236}, {2, 3, 8, 1, 2.0241, 7.912}, {4, 1, 8, 1, 1.2746, 5.825},
+      {4, 2, 4, 1, 1.3875, 6.447}, {4, 2, 8, 1, 2.1737, 8.555}, {4, 3, 4, 1, 1.9115, 7.957}};
+  Choice best{true, 2, 3, 1, -4};
   double best_cost = 1e300;
-  for (const auto& c : cand) {
-    const int mt = c[0], t = c[1], kw = c[2];
-    const int slab = kw * mt * 8192, red = (kw > 4 ? kw / 2 : kw) * t * mt * 4096;
-    const int resident = 160 * 1024 / (slab > red ? slab : red);  // workgroups a CU holds at once (LDS)
-    const long long wgs = (long long)ceil_div(ceil_div(N, 32), t) * ceil_div(M, 32 * mt) * batch;
-    const double load = (double)((wgs + 255) / 256);
-    const double mfma = KB * 8 * t * mt * 32 / 4, conv = KB * 8 * t * 13 * 4 / 4, issue = KB * 8 * t * mt * 8 / 4;
-    const double comp = (kw == 8 || resident > 1) ? (mfma > 1.2 * (conv + issue) ? mfma : 1.2 * (conv + issue))
-                                                  : mfma + 0.6 * conv;
-    const double mem = (32.0 * mt * K * 2 + 32.0 * t * K / 2) / 48;
-    const double body = comp > mem ? comp : mem;
-    const double fixed = 9000 * (kw == 8 ? 1.3 : 1.0);
-    const double cost = resident > 1 ? load * body + fixed * (double)(((long long)load + resident - 1) / resident)
-                                     : load * (body + fixed);
-    if (cost < best_cost) best_cost = cost, best = Choice{true, mt, t, 1, -kw};
-  }
-  return best;
-}
-
-// Launch shape of the shared-slab 32x32x16 kernel (gemm_wide_shared_kernel) above 256 rows: whole rounds
-// of 256 workgroups times a workgroup's time, which is its tile area over the rate a busy CU sustains
-// with that shape (measured at 4096 rows on 4096 x 11008, relative to the 128 x 256 tile) plus a fixed
-// prologue / epilogue share (about an eighth of a 128 x 256 workgroup's time at K = 4096).
-Choice choose_wide_shared(int M, int K, int N, int batch) {
-  static const int cand[][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}, {2, 3}};
-  static const double rate[] = {1.0, 1.048, 0.854, 0.905, 0.914};
-  Choice best{true, 4, 1, 8, -1};
-  double best_cost = 1e300;
-  for (int i = 0; i < 5; ++i) {
-    const int mt = cand[i][0], t = cand[i][1];
-    const long long wgs = (long long)ceil_div(ceil_div(N, 32), t * 8) * ceil_div(M, 32 * mt) * batch;
-    const double cost = (double)((wgs + 255) / 256) * (mt * t / rate[i] + 0.5 * 4096.0 / K);
-    if (cost < best_cost) best_cost = cost, best = Choice{true, mt, t, 8, -1};  // a = nw, b = -1: the shared-slab kernel
+  for (const Shape& c : shapes) {
+    if (c.kw == 1 && K < 256) continue;  // the shared-slab kernel needs two blocks
+    const long long wgs = (long long)ceil_div(ceil_div(N, 32), c.t * c.nw) * ceil_div(M, 32 * c.mt) * batch;
+    const double cost = (double)((wgs + 255) / 256) * (K / 128.0 * c.a + c.b);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c.kw == 1 ? Choice{true, c.mt, c.t, c.nw, -1} : Choice{true, c.mt, c.t, 1, -c.kw};
+    }
   }
   return best;
 }
@@ -2081,20 +2071,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   // tile is 16 gate + 16 up columns: as many tiles, and the same launch shapes, as the plain GEMM on N columns.)
   const bool wide_ok = K % 128 == 0 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
                        (long long)M * K < (1LL << 31);
-  // 33-256 rows: 10-40 % faster than the 16x16x32 kernels on every layer shape measured
-  if (wide_ok && M > 32 && M <= 256) return choose_wide(M, K, N, batch);
-  // 21-32 rows of a single problem: its one-row-tile shapes beat the 16x16x32 kernels by 5-25 % from K = 2048 up
-  // (at 24 / 32 rows, 4096 x 11008: 10.2 / 10.6 against 11.6 / 11.6 us; 4096 x 4096: 7.8 / 7.9 against 9.5 / 9.8;
-  // 4096 x 14336: 11.0 / 11.4 against 14.6 / 14.8; 8192 x 1280: 12.0 against 15.4; 4096 x 1376: 7.7 / 7.8 against
-  // 9.2 / 10.6); with at most 128 column tiles (4096 columns) twice as many workgroups of one tile each do better
-  // still (11008 x 4096: 19.0 / 20.0 against 20.4 / 20.5).  At 17 rows the streaming kernel, whose cost grows with
-  // the rows, is still ahead on narrow layers and long K (11008 x 4096: 16.4 against 18.9), and at K = 1024 always.
-  if (wide_ok && batch == 1 && M > W4A16_WIDE_FROM && M <= 32 && K >= 2048) {
-    if (ceil_div(N, 32) <= 128) return Choice{true, 2, 1, 1, -8};
-    return choose_wide(M, K, N, batch);
-  }
-  // more rows: one activation slab shared by the workgroup's eight waves, wide tiles
-  if (wide_ok && M > 256 && K >= 256) return choose_wide_shared(M, K, N, batch);
+  // From 33 rows: 10-40 % faster than the 16x16x32 kernels on every layer shape measured, and ahead of
+  // dequantise + dense GEMM at every row count.
+  if (wide_ok && M > 32) return choose_mfma32(M, K, N, batch);
+  // 21-32 rows of a single problem: 5-25 % over the 16x16x32 kernels from K = 2048 up (at 24 / 32 rows,
+  // 4096 x 11008: 10.2 / 10.6 against 11.6 / 11.6 us; 4096 x 4096: 7.8 / 7.9 against 9.5 / 9.8; 4096 x 14336:
+  // 11.0 / 11.4 against 14.6 / 14.8; 8192 x 1280: 12.0 against 15.4; 4096 x 1376: 7.7 / 7.8 against 9.2 / 10.6).
+  // At 17 rows the streaming kernel, whose cost grows with the rows, is still ahead on narrow layers and long K
+  // (11008 x 4096: 16.4 against 18.9), and at K = 1024 always.
+  if (wide_ok && batch == 1 && M > W4A16_WIDE_FROM && K >= 2048) return choose_mfma32(M, K, N, batch);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;
   // 24-32 rows: the LDS-staged kernel's 2-row-tile shapes beat the streaming kernel by ~12 % where K
