@@ -169,7 +169,8 @@ int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const
 /*
  * w4a16_gemm_packed_f16_batched with an explicit launch shape, for tuning and tests:
  * (mt, t, a, 0) = the streaming kernel with a waves (see w4a16_gemm_packed_f16_cfg),
- * (mt, t, a, b) with b > 0 = the LDS-staged kernel with nw = a, kw = b.
+ * (mt, t, a, b) with b > 0 = the LDS-staged kernel with nw = a, kw = b,
+ * (mt, t, 1, -kw) = the 32x32x16 kernel with private slabs, (mt, t, nw, -1) with nw > 1 = the one with a shared slab.
  */
 int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, const void* packed_w,
                                       const void* packed_sz, const void* bias, void* out,

@@ -34,7 +34,7 @@ def make_problems(E, M, K, N, G, seed, shared):
     return xs, [w[1:] for w in ws]
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 33, 70])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 70, 300])
 @pytest.mark.parametrize("shared", [True, False])
 def test_batched_through_c_abi(L, cuda, M, shared):
     E, K, N, G = 3, 384, 208, 128
@@ -69,6 +69,17 @@ def test_batched_through_c_abi(L, cuda, M, shared):
     # with it the order of the fp32 additions: agreement within one fp16 ulp of the larger result
     a, b = got.astype(np.float32), single.cpu().numpy().astype(np.float32)
     assert np.abs(a - b).max() <= 2.0**-10 * max(1.0, np.abs(b).max())
+    if M >= 33:
+        # both 32x32x16 kernels as batched launches, whatever the default was: private slabs (mt, t, 1, -kw)
+        # and shared slab (mt, t, nw, -1)
+        for cfg in ((2, 3, 1, -8), (1, 3, 1, -4), (4, 1, 8, -1), (2, 3, 8, -1), (4, 3, 4, -1)):
+            out2 = torch.full((E, M, N), float("nan"), dtype=torch.float16, device=cuda)
+            L.check(lib.w4a16_gemm_packed_f16_batched_cfg(tx.data_ptr(), 0 if shared else M * K, pw.data_ptr(),
+                                                          ps.data_ptr(), tb.data_ptr(), out2.data_ptr(), M * N, M, K, N,
+                                                          G, E, *cfg, stream), "batched_cfg")
+            c = out2.cpu().numpy().astype(np.float32)
+            assert not np.isnan(c).any(), cfg
+            assert np.abs(c - b).max() <= 2.0**-10 * max(1.0, np.abs(b).max()), cfg
 
 
 def test_batched_argument_errors(L, cuda):
