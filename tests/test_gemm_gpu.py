@@ -315,6 +315,21 @@ def test_full_size_stock_layout_kernel(abi, cuda, full):
         assert (bits(ye) == bits(full["w"][ks[:m]])).all()
 
 
+def test_full_size_every_32x32x16_shape_repeats_bit_for_bit(abi, L, cuda, full):
+    """Many rows of the full-size layer (several workgroups per CU, all of them busy): every launch shape of the two
+    32x32x16 kernels must give the same bits on every run (their LDS-DMA is ordered by hand-counted waits: a
+    miscount shows up as a sporadic difference, not as a wrong shape) and agree with the default within an fp16 ulp."""
+    x = dev_t(orc.make_inputs(1300, full["K"], full["N"], full["G"], seed=4300)[0], cuda)
+    ref = abi.gemm_packed(x, full["packed"]).float()
+    scale = max(1.0, float(ref.abs().max()))
+    shapes = [("wide", ) + c for c in L.built_shapes(2)] + [("wide", mt, t, -nw) for mt, t, nw in L.built_shapes(3)]
+    for cfg in shapes:
+        first = abi.gemm_packed(x, full["packed"], cfg=cfg)
+        assert float((first.float() - ref).abs().max()) <= 2.0**-9 * scale, cfg
+        for _ in range(5):
+            assert torch.equal(abi.gemm_packed(x, full["packed"], cfg=cfg), first), cfg
+
+
 def test_full_size_dequantize_bit_exact(abi, full):
     assert (bits(abi.dequant(full["tqw"], full["ts"], full["tqz"]).cpu().numpy()) == bits(full["w"])).all()
     assert (bits(abi.dequant_packed(full["packed"]).cpu().numpy()) == bits(full["w"])).all()

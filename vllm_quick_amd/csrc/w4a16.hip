@@ -1220,8 +1220,17 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 // instructions: with MT = 4 the conversion takes a quarter of the vector issue slots of the 16x16x32
 // kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
 // landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
+// Slabs in the ring of gemm_wide_shared_kernel: three (the DMA runs two blocks ahead) for workgroups that have a CU to
+// themselves; two for the 4-wave shape that leaves registers and LDS for a second workgroup on the CU, whose
+// arithmetic then covers the first one's waits, prologue and stores.
+#ifndef W4A16_RING2
+#define W4A16_RING2 1
+#endif
+template <int MT, int T, int NW>
+constexpr int ring_slabs() { return (W4A16_RING2 && NW == 4 && MT * T <= 8) ? 2 : 3; }
+
 template <int MT, int T, int NW, int SZS, bool ACT = false>
-__global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
+__global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1)) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
                                                                    const GemmArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   fetch_args_now(ga);
@@ -1235,6 +1244,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   constexpr int ND = PIECES / NW;           // ... per wave
   constexpr int NSZ = 4 / SZS;
   constexpr int WL = T * (NSZ + 2);         // register loads per weight block and wave
+  constexpr int RING = ring_slabs<MT, T, NW>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int lane = threadIdx.x & 63;
@@ -1352,11 +1362,13 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   // DMA 0/1: whether D(i+2) exists; LW: whether W(i+1) exists.
   auto block = [&](auto dma, auto lw, int i, const WSet& cur, WSet& nxt) {
     constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
-    const int base = (i % 3) * SLAB + xrd;
-    wait_vmcnt<LW ? ND + WL : WL>();
+    const int base = (i % RING) * SLAB + xrd;
+    // (two slabs: D(i+1) is issued after this barrier, so only W(i) is younger than D(i))
+    wait_vmcnt<(LW && RING == 3) ? ND + WL : WL>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DMA) dma_x(i + 2, (i + 2) % 3);
+    if constexpr (DMA) dma_x(i + RING - 1, (i + RING - 1) % RING);
+    __builtin_amdgcn_sched_barrier(0);  // the wait counts above rely on this issue order: DMA first, then weights
     if constexpr (LW) load_w(i + 1, nxt);
     __builtin_amdgcn_sched_barrier(0);
     SZ c[T];
@@ -1379,7 +1391,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
   const int n = a.KB;  // >= 2 (host-checked)
   WSet w0, w1;
   dma_x(0, 0);
-  dma_x(1, 1);
+  if constexpr (RING == 3) dma_x(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
   load_w(0, w0);
   __builtin_amdgcn_sched_barrier(0);
   int i = 0;
@@ -1392,7 +1405,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_wide_shared_kernel(int n_slices,
     w0 = w1;
     ++i;
   }
-  block(Flag<0>{}, Flag<1>{}, i, w0, w1);
+  block(Flag<RING == 2>{}, Flag<1>{}, i, w0, w1);  // (two slabs: the last block's slab is still to be fetched)
   block(Flag<0>{}, Flag<0>{}, i + 1, w1, w0);
 
   // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
@@ -1947,7 +1960,7 @@ int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int b
 
 template <int MT, int T, int NW>
 int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
-  constexpr int lds = 3 * MT * 32 * 256;  // ring of three slabs
+  constexpr int lds = ring_slabs<MT, T, NW>() * MT * 32 * 256;  // ring of slabs
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks, at least two of them, and 32-bit byte offsets into the three buffers
   if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
@@ -2036,8 +2049,8 @@ struct Choice {
 //   ceil(workgroups / 256 CUs) x (K / 128 x a + b)   microseconds,
 // a (per 128-k block) and b (prologue, reduction, stores) per shape, fitted by least squares on all fifteen
 // shapes x 14 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral, 2/4/8-way shards of the
-// benchmark layer) x 24-4096 rows (scripts/exp_shared_sweep.py): mean loss against the best built shape 0.6 %,
-// worst 12 %; with each layer shape held out of the fit in turn, 0.5 % and 12 %.  The private-slab kernel splits K
+// benchmark layer) x 24-4096 rows (scripts/exp_shared_sweep.py): mean loss against the best built shape 1.1 %,
+// worst 12 %; with each layer shape held out of the fit in turn, 1.1 % and 12 %.  The private-slab kernel splits K
 // over the waves of a workgroup, so it keeps many workgroups on narrow layers at any row count (8192 x 1280 at
 // 512 rows: 20 us against 58 for the best shared-slab shape); the shared-slab kernel wins where rows x columns
 // alone fill the chip.
@@ -2047,10 +2060,10 @@ Choice choose_mfma32(int M, int K, int N, int batch) {
     double a, b;
   };
   static const Shape shapes[] = {
-      {1, 2, 1, 8, 0.1707, 1.339}, {1, 3, 1, 4, 0.2491, 1.322}, {1, 3, 1, 8, 0.2275, 2.981}, {2, 1, 1, 8, 0.1879, 2.008},
-      {2, 2, 1, 4, 0.2536, 2.083}, {2, 2, 1, 8, 0.2408, 3.344}, {2, 3, 1, 4, 0.3149, 3.871}, {2, 3, 1, 8, 0.2981, 4.660},
-      {2, 1, 8, 1, 0.8765, 3.995}, {2, 2, 8, 1, 1.4621, 6.236}, {2, 3, 8, 1, 2.0241, 7.912}, {4, 1, 8, 1, 1.2746, 5.825},
-      {4, 2, 4, 1, 1.3875, 6.447}, {4, 2, 8, 1, 2.1737, 8.555}, {4, 3, 4, 1, 1.9115, 7.957}};
+      {1, 2, 1, 8, 0.1730, 1.378}, {1, 3, 1, 4, 0.2506, 1.434}, {1, 3, 1, 8, 0.2341, 3.025}, {2, 1, 1, 8, 0.1913, 2.045},
+      {2, 2, 1, 4, 0.2547, 2.210}, {2, 2, 1, 8, 0.2444, 3.492}, {2, 3, 1, 4, 0.3181, 4.032}, {2, 3, 1, 8, 0.3005, 4.867},
+      {2, 1, 8, 1, 0.8776, 4.211}, {2, 2, 8, 1, 1.4627, 6.527}, {2, 3, 8, 1, 2.0270, 8.208}, {4, 1, 8, 1, 1.2832, 6.042},
+      {4, 2, 4, 1, 1.3471, 6.449}, {4, 2, 8, 1, 2.1858, 8.772}, {4, 3, 4, 1, 1.8948, 8.294}};
   Choice best{true, 2, 3, 1, -4};
   double best_cost = 1e300;
   for (const Shape& c : shapes) {
