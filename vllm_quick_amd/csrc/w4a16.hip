@@ -1112,6 +1112,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
     load_w(kb, w0);
     __builtin_amdgcn_sched_barrier(0);
     dma_x(kb, 0);
+    __builtin_amdgcn_sched_barrier(0);  // half 0 before half 1: the counted waits rely on the issue order
     dma_x(kb, 1);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
