@@ -42,7 +42,8 @@ enum {
   W4A16_E_SHAPE = -5,     /* M, K, N or G is not positive, or K is not a multiple of 32         */
   W4A16_E_ALIGN = -6,     /* a pointer is not 16-byte aligned                                   */
   W4A16_E_LAUNCH = -7,    /* the HIP runtime refused the launch; see w4a16_last_hip_error()     */
-  W4A16_E_TOO_LARGE = -8  /* an index would overflow 32 bits                                    */
+  W4A16_E_TOO_LARGE = -8, /* an index would overflow 32 bits                                    */
+  W4A16_E_WORKSPACE = -9  /* the workspace is smaller than the launch shape asked for needs     */
 };
 
 /* Human-readable text for a return code (host pointer, static storage). */
@@ -219,6 +220,40 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
+ * The decode kernel (up to 4 rows) with an explicit launch shape, for tuning and tests; batching and epilogues as
+ * for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
+ * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
+ * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and stages its activations in a private
+ * piece of LDS.  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
+ * `workspace`, and the one that arrives last adds them in split order, so the result does not depend on timing.
+ * `workspace` (16-byte aligned; may be NULL when splits == 1) must hold w4a16_decode_workspace_bytes(...) bytes,
+ * zero before its first use: the kernels return every counter they touch to zero, so one buffer serves any
+ * sequence of launches, but only one launch at a time.  Built (t, waves) only, W4A16_E_SHAPE otherwise;
+ * W4A16_E_WORKSPACE if the buffer is too small.  No counterpart in the reference, whose split over K goes
+ * through a [split_k, M, N] tensor and a separate sum (gemm_kernels.cu:420-445).
+ */
+int w4a16_gemm_packed_f16_decode_cfg(const void* x, long long x_batch_stride, const void* packed_w,
+                                     const void* packed_sz, const void* bias, void* out,
+                                     long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                     int epilogue, int t, int waves, int depth, int splits, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+size_t w4a16_decode_workspace_bytes(int K, int N, int batch, int epilogue, int t, int waves, int splits);
+
+/*
+ * w4a16_gemm_packed_f16_ex with the library's launch shape and an optional workspace (NULL: exactly
+ * w4a16_gemm_packed_f16_ex with mt == 0).  With a workspace of at least w4a16_workspace_bytes(...) bytes the
+ * library may split K over workgroups where the plain launch would leave most of the chip idle (few columns,
+ * long K, up to 4 rows: the per-rank qkv projection of a tensor-parallel model at decode).  Same rules for the
+ * buffer as above; a buffer that is too small is ignored.  w4a16_workspace_bytes returns 0 where no split is
+ * chosen.  w4a16_launch_shape_ws reports the choice made with a workspace (W4A16_KERNEL_DECODE: (1, t, waves, splits)).
+ */
+size_t w4a16_workspace_bytes(int M, int K, int N, int G, int batch, int epilogue);
+int w4a16_gemm_packed_f16_ws(const void* x, long long x_batch_stride, const void* packed_w, const void* packed_sz,
+                             const void* bias, void* out, long long out_batch_stride, int M, int K, int N, int G,
+                             int batch, int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+int w4a16_launch_shape_ws(int M, int K, int N, int G, int batch, int epilogue, int shape[5]);
+
+/*
  * Which kernel and launch shape w4a16_gemm_packed_f16 / _batched / _ex pick by themselves for a problem
  * (pure host arithmetic; for benchmarks, profiles and tests that need to name what ran).  No counterpart
  * in the reference, whose launch shape is fixed (gemm_kernels.cu:422-444).
@@ -227,14 +262,17 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
  *                LDS_STAGED  (mt, t, nw, kw)        16-row / 16-column tiles
  *                MFMA32      (mt, t, 1, kw)         32-row / 32-column tiles, private slabs per wavefront
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
+ *                DECODE      (1, t, waves, splits)  up to 4 rows
  */
-enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFMA32 = 2, W4A16_KERNEL_MFMA32_SHARED = 3 };
+enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFMA32 = 2, W4A16_KERNEL_MFMA32_SHARED = 3,
+       W4A16_KERNEL_DECODE = 4 };
 int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5]);
 
 /*
  * Enumerates the launch shapes this build holds of kernel `kernel` (W4A16_KERNEL_*): shape number `index`
  * (0, 1, ..) in the order of the arguments the _cfg entry points take - STREAMING (mt, t, waves),
- * LDS_STAGED (mt, t, nw, kw), MFMA32 (mt, t, kw), MFMA32_SHARED (mt, t, nw); W4A16_E_SHAPE past the last one.
+ * LDS_STAGED (mt, t, nw, kw), MFMA32 (mt, t, kw), MFMA32_SHARED (mt, t, nw), DECODE (t, waves); W4A16_E_SHAPE past
+ * the last one.
  * Lets a test suite run every shape that exists instead of a list kept by hand.  No counterpart in the reference.
  */
 int w4a16_built_shape(int kernel, int index, int shape[4]);

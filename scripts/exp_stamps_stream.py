@@ -9,7 +9,10 @@ from vllm_quick_amd._C import ops
 from bench import make_weights, make_x
 
 dev = torch.device("cuda:0")
-cfg = tuple(int(v) for v in sys.argv[1].split(","))
+decode = sys.argv[1].startswith("d")   # "d3,16": the decode kernel with t = 3, 16 waves
+cfg = tuple(int(v) for v in sys.argv[1].lstrip("d").split(","))
+if decode:
+    cfg = ("decode", cfg[0], cfg[1], 1)
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 K, N, G = 4096, 11008, 128
 packs = [ops.awq_repack(*make_weights(K, N, G, i, dev)) for i in range(16)]
@@ -19,7 +22,7 @@ for rep in range(40):   # warm clocks, rotate weights so HBM is really read
         ops.awq_gemm_packed(x, p, cfg=cfg)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-mt, t, W = cfg
+mt, t, W = (1, cfg[1], cfg[2]) if decode else cfg
 ctas = -(-(-(-N // 16)) // t) * -(-M // (mt * 16))
 buf = np.zeros(4096 * 32, dtype=np.uint64)
 rc = lib.w4a16_dbg_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
@@ -34,6 +37,13 @@ def stat(name, v):
 print(f"cfg {cfg} M={M}: {len(st)} waves, {blocks} blocks per wave")
 stat("start after first wave", st[:, 0] - t0)
 stat("setup + loads issued", st[:, 1] - st[:, 0])
+if decode:
+    stat("first block's weights requested", st[:, 13] - st[:, 0])
+    stat("address setup done", st[:, 14] - st[:, 0])
+    stat("LDS-DMA issued", st[:, 15] - st[:, 0])
+    for wv in (0, 4, 8, 12):
+        sel = st[wid == wv]
+        print(f" w{wv}: first weights {np.median(sel[:, 13] - sel[:, 0]):.0f} setup {np.median(sel[:, 14] - sel[:, 0]):.0f} dma {np.median(sel[:, 15] - sel[:, 0]):.0f} all requested {np.median(sel[:, 1] - sel[:, 0]):.0f}")
 prev = st[:, 1]
 for b in range(min(blocks, 8)):
     stat(f"block {b} done after previous", st[:, 2 + b] - prev)

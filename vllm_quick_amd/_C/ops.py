@@ -121,11 +121,25 @@ def awq_repack(kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch
     return PackedAWQ(pw, ps, K, N, G)
 
 
+def gemm_workspace(device: torch.device, nbytes: int = 4 << 20) -> torch.Tensor:
+    """A zeroed device buffer for launches that split K over workgroups (partial sums and ticket counters).
+
+    Zero it once: the kernels return every counter they used to zero.  One workspace serves any number of
+    layers, but only one launch at a time (launches on different streams need one each)."""
+    return torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _check_workspace(workspace: torch.Tensor, device: torch.device) -> None:
+    if not workspace.is_cuda or workspace.device != device or not workspace.is_contiguous():
+        raise RuntimeError("workspace must be a contiguous tensor on the device of the activations")
+
+
 def awq_gemm_packed(in_feats: torch.Tensor,
                     packed: PackedAWQ,
                     bias: Optional[torch.Tensor] = None,
-                    cfg: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
-    """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves), (mt, t, nw, kw) for the LDS-staged kernel or ("wide", mt, t, kw) for the 32x32x16 kernel overrides the launch shape."""
+                    cfg: Optional[Tuple[int, int, int]] = None,
+                    workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves), (mt, t, nw, kw) for the LDS-staged kernel, ("wide", mt, t, kw) for the 32x32x16 kernel or ("decode", t, waves, splits) for the decode kernel overrides the launch shape.  `workspace` (see `gemm_workspace`) lets the library split K over workgroups where that pays."""
     _require(in_feats, torch.float16, "in_feats")
     if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
         raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
@@ -144,9 +158,28 @@ def awq_gemm_packed(in_feats: torch.Tensor,
         out = torch.empty((M, packed.N), dtype=torch.float16, device=x.device)
         if M == 0:
             return out
-        if cfg is None:
+        if cfg is None and workspace is not None:
+            _check_workspace(workspace, x.device)
+            rc = lib.w4a16_gemm_packed_f16_ws(x.data_ptr(), 0, packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
+                                              bias_ptr, out.data_ptr(), 0, M, packed.K, packed.N, packed.G, 1, 0,
+                                              workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                              _stream())
+        elif cfg is None:
             rc = lib.w4a16_gemm_packed_f16(x.data_ptr(), packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(),
                                            bias_ptr, out.data_ptr(), M, packed.K, packed.N, packed.G, _stream())
+        elif cfg[0] == "decode":  # ("decode", t, waves, splits): up to 4 rows
+            _, t, waves, splits = cfg[:4]
+            depth = cfg[4] if len(cfg) > 4 else 0  # blocks a wave keeps in flight (0: the library's default)
+            if splits > 1 and workspace is None:
+                workspace = gemm_workspace(x.device, lib.w4a16_decode_workspace_bytes(packed.K, packed.N, 1, 0, t, waves, splits))
+            ws_ptr, ws_bytes = (None, 0)
+            if workspace is not None:
+                _check_workspace(workspace, x.device)
+                ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+            rc = lib.w4a16_gemm_packed_f16_decode_cfg(x.data_ptr(), 0, packed.packed_w.data_ptr(),
+                                                      packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), 0, M,
+                                                      packed.K, packed.N, packed.G, 1, 0, t, waves, depth, splits, ws_ptr,
+                                                      ws_bytes, _stream())
         elif cfg[0] == "wide":  # the 32x32x16 kernel: ("wide", mt, t, kw), tiles of 32 rows / 32 columns
             _, mt, t, kw = cfg
             rc = lib.w4a16_gemm_packed_f16_wide_cfg(x.data_ptr(), packed.packed_w.data_ptr(),

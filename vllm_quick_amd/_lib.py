@@ -44,6 +44,13 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16_masked": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                      [c_int] * 6 + [c_void_p, c_int, c_void_p]),
     "w4a16_dequantize_packed_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "w4a16_gemm_packed_f16_decode_cfg": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
+                                         [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    "w4a16_decode_workspace_bytes": (c_size_t, [c_int] * 7),
+    "w4a16_workspace_bytes": (c_size_t, [c_int] * 6),
+    "w4a16_gemm_packed_f16_ws": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
+                                 [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "w4a16_launch_shape_ws": (c_int, [c_int] * 6 + [ctypes.POINTER(c_int)]),
     "w4a16_launch_shape": (c_int, [c_int] * 5 + [ctypes.POINTER(c_int)]),
     "w4a16_built_shape": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "w4a16_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -63,6 +70,8 @@ def _load() -> ctypes.CDLL:
         try:
             fn = getattr(lib, name)
         except AttributeError as e:  # pragma: no cover - build mismatch
+            if os.environ.get("W4A16_LIBRARY"):
+                continue  # an experiment build of an older revision: the symbol is simply not callable
             raise ImportError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = restype
         fn.argtypes = argtypes
@@ -74,7 +83,8 @@ def _load() -> ctypes.CDLL:
 lib = _load()
 
 
-KERNEL_NAMES = {0: "gemm_packed_kernel", 1: "gemm_tiled_kernel", 2: "gemm_wide_kernel", 3: "gemm_wide_shared_kernel"}
+KERNEL_NAMES = {0: "gemm_packed_kernel", 1: "gemm_tiled_kernel", 2: "gemm_wide_kernel", 3: "gemm_wide_shared_kernel",
+                4: "gemm_decode_kernel"}
 
 
 def launch_shape(M: int, K: int, N: int, batch: int = 1, epilogue: int = 0) -> str:

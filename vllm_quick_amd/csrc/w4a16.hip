@@ -60,6 +60,12 @@
 #ifndef W4A16_WIDE_FROM
 #define W4A16_WIDE_FROM 20  // the 32x32x16 kernel serves single problems with more rows than this
 #endif
+#ifndef W4A16_DECODE
+#define W4A16_DECODE 1  // the decode kernel serves up to 4 rows by default
+#endif
+#ifndef W4A16_DECODE_DEPTH16
+#define W4A16_DECODE_DEPTH16 1  // blocks in flight per wave of a 16-wave decode workgroup
+#endif
 #ifndef W4A16_ILV
 #define W4A16_ILV 1  // the 32x32x16 kernel deals matrix and conversion instructions out alternately
 #endif
@@ -188,6 +194,11 @@ struct GemmArgs {
   // Batched launches (gridDim.z problems of one shape): element strides from one problem to the
   // next; all zero for a single GEMM.  x_bs == 0 shares the activations between the problems.
   long long x_bs, out_bs, pw_bs, psz_bs, bias_bs;
+  // Worked out by the host once instead of by every wave (the waves of a workgroup share one scalar unit, and
+  // an integer division is ~35 of its instructions):
+  int batched;   // more than one problem in the launch (else the strides above are not even looked at)
+  int g_magic;   // group sizes that are multiples of 128: group of block kb = (kb * g_magic) >> 16; 0: divide
+  int mb_magic;  // kernels with row blocks, one panel: j / m_blocks = (j * mb_magic) >> 16; 0: divide
 };
 
 // Makes the compiler fetch the whole argument block in one batch of scalar loads at kernel entry.
@@ -197,12 +208,21 @@ struct GemmArgs {
 __device__ __forceinline__ void fetch_args_now(const GemmArgs& g) {
   asm volatile("" ::"s"(g.x), "s"(g.pw), "s"(g.psz), "s"(g.bias), "s"(g.out), "s"(g.M), "s"(g.K), "s"(g.N),
                "s"(g.G), "s"(g.NT), "s"(g.KB), "s"(g.NG), "s"(g.KBS), "s"(g.add_out), "s"(g.mask));
-  asm volatile("" ::"s"(g.x_bs), "s"(g.out_bs), "s"(g.pw_bs), "s"(g.psz_bs), "s"(g.bias_bs));
+  asm volatile("" ::"s"(g.x_bs), "s"(g.out_bs), "s"(g.pw_bs), "s"(g.psz_bs), "s"(g.bias_bs), "s"(g.batched),
+               "s"(g.g_magic), "s"(g.mb_magic));
+}
+
+// Group of k (a multiple of 32) for kernels whose scale/zero words cover SZS k-steps of 32.
+template <int SZS>
+__device__ __forceinline__ int group_of(const GemmArgs& a, int k) {
+  if (SZS == 4 && a.g_magic != 0) return ((k >> 7) * a.g_magic) >> 16;
+  return k / a.G;
 }
 
 // The argument block of problem blockIdx.z of a batched launch (scalar arithmetic only).
 __device__ __forceinline__ GemmArgs batch_slice(const GemmArgs& g) {
   GemmArgs a = g;
+  if (!g.batched) return a;
   const long long b = blockIdx.z;
   a.x = g.x + b * g.x_bs;
   a.pw = g.pw + b * g.pw_bs;
@@ -314,7 +334,7 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int s = 0; s < NSZ; ++s) {
-        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
         b.sz[t][s] = szp[t][g * 16];
       }
 #pragma unroll
@@ -545,6 +565,288 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   STAMP(12);
 }
 
+// A compile-time switch passed as a lambda argument.
+template <int V>
+struct Flag {
+  static constexpr int value = V;
+};
+
+// Waits until at most N of the wave's vector-memory operations (which complete in issue order) are outstanding.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------
+// Decode GEMM on the private layout: up to 4 rows, paced weight stream, optional K split over workgroups
+// ---------------------------------------------------------------------------
+// The streaming kernel above requests everything a wave will ever need at once, activations and scale/zero
+// words included, in fragment-shaped loads: at one row a wave of the 4096 x 11008 launch issues 20 vector-memory
+// instructions for 6 KiB of weights, a CU holds only so many bytes in flight (about 50-60 KiB), and requests
+// are admitted oldest wave first, so the youngest waves of a workgroup get theirs in thousands of cycles after
+// the oldest, receive their data last and still have all of their arithmetic to do after the last byte.
+//
+// Here only the weights travel through registers.  A wave's activations (its k-blocks x up to 4 rows x 256
+// bytes) and its scale/zero words (64 bytes per tile and group) go to a private piece of LDS by LDS-DMA once,
+// ahead of the weights, in one or two instructions with only the lanes that carry something switched on, and
+// come back as ds_read_b128 B fragments and ds_read_b32 constants.  Chunk c of activation row r sits at
+// 16-byte position c ^ 4r of the row's 256 bytes, so the rows a fragment read touches fall into different banks.
+// The weights come in units of 1 KiB (one tile's 128-k block, one instruction); a wave keeps DB blocks of T
+// units in flight and asks for the unit DB blocks ahead as soon as it has consumed a unit.
+//
+// gridDim.y > 1 splits K over workgroups: each writes its fp32 partial sums (after the usual reduction over
+// its own waves) to its slot of `ws`, takes a ticket, and the workgroup that draws the last ticket of an
+// output slot adds the slots in split order (so the result does not depend on who came last), applies the
+// epilogue, stores, and returns the ticket counter to zero for the next launch.
+// Launch constants of the decode kernel the host works out once, so that the 16 waves of a workgroup, which
+// share one scalar unit, do not each derive them again before their first load can go out.
+struct DecodeArgs {
+  f32x4* ws;          // K-split launches: partial sums
+  unsigned* tickets;  // K-split launches: arrival counters
+  int kb_per_split;   // 128-k blocks per workgroup
+  int nb_max;         // most blocks any wave takes
+  int wstride;        // bytes of one column tile in packed_w
+  int sstride;        // bytes of one column tile in packed_sz
+};
+
+template <int T, int W, int DB, int SZS, bool ACT = false>
+__global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  fetch_args_now(ga);
+  asm volatile("" ::"s"(e.ws), "s"(e.tickets), "s"(e.kb_per_split), "s"(e.nb_max), "s"(e.wstride), "s"(e.sstride));
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
+  const GemmArgs a = batch_slice(ga);
+  constexpr int NSZ = 4 / SZS;             // scale/zero words per 128-k block and tile
+  constexpr int UL = NSZ + 1;              // vector-memory loads per unit
+  constexpr int H = ACT ? T / 2 : T;       // tiles per half
+  static_assert(DB == 1 || DB == 2, "one or two blocks in flight");
+  static_assert(!ACT || T % 2 == 0, "gate and up tiles come in pairs");
+  static_assert(H <= 4, "one wave finishes all tiles: 16 lanes per tile or tile pair");
+  const int NTH = ACT ? a.NT / 2 : a.NT;   // column tiles per half
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int nb_max = e.nb_max;
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15;
+  const int kq = lane >> 4;
+  const int nt0 = blockIdx.x * H;
+#ifdef W4A16_STAMPS
+  constexpr int NWAVES = W;
+  int n_done = 0;
+#endif
+  STAMP(0);
+  // this workgroup's k-blocks [kb_lo, kb_hi); this wave's: kb0, kb0 + W, ..
+  const int kb_lo = blockIdx.y * e.kb_per_split;
+  const int kb_hi = min(kb_lo + e.kb_per_split, a.KB);
+  const int kb0 = kb_lo + w;
+  const int nblk = kb0 < kb_hi ? (kb_hi - kb0 + W - 1) / W : 0;
+
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, a.NT * e.wstride, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * e.sstride, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  // Uniform byte offsets of the workgroup's tiles (tiles past the end re-read the last one; their results are
+  // dropped); the per-lane parts are the same for every tile and block.
+  int wbase[T], szbase[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int nt = min(nt0 + (t % H), NTH - 1) + (t / H) * NTH;
+    wbase[t] = nt * e.wstride;
+    szbase[t] = nt * e.sstride;
+  }
+  const uint32_t wlane = lane * 16u, szlane = n16 * 4u;
+  // LDS-DMA of one block's activations (1 KiB of the wave's private LDS): lane -> row lane >> 4 (rows past
+  // M - 1 repeat it), 16-byte position lane & 15 of the row, which holds chunk (lane & 15) ^ 4 (lane >> 4)
+  const uint32_t xlane = ((uint32_t)min(kq, a.M - 1) * a.K + ((n16 ^ (4 * kq)) * 8)) * 2u;
+  const int xwave = w * nb_max * 1024;
+  // B fragment of k-step j: row min(n16, M - 1) (the matrix instruction's columns past M - 1 are never stored),
+  // chunk 4 j + kq
+  int xrd[4];
+  {
+    const int rr = min(n16, a.M - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xrd[j] = xwave + rr * 256 + ((4 * (j ^ rr) + kq) << 4);
+  }
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const DqConst dqc = make_dq_const();
+
+  struct Unit {
+    uint32_t sz[NSZ];
+    u32x4 q;
+  };
+  auto load_unit = [&](int t, int kb, Unit& d) {
+#pragma unroll
+    for (int s = 0; s < NSZ; ++s) {
+      // the host admits group sizes of 32, 64 and multiples of 128 only
+      const int g = SZS == 4 ? (kb * a.g_magic) >> 16 : kb * NSZ + s;
+      d.sz[s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szlane, szbase[t] + g * 64, 0);
+    }
+    d.q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wlane, wbase[t] + kb * 1024, 2));  // nt
+  };
+  auto compute_unit = [&](int t, const Unit& d, const f16x8 (&xf)[4]) {
+    SZ c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j % SZS == 0) c = expand_sz(d.sz[j / SZS]);
+      const f16x8 af = dequant_word(d.q[j], c, dqc);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[j], acc[t], 0, 0, 0);
+    }
+  };
+  // One block from the registers `u`; with REFILL each unit's registers are asked to fetch the same tile's unit
+  // of block kb_refill as soon as the unit is consumed.  (A compile-time flag: a load under a run-time branch
+  // makes the compiler wait for every load in flight.)
+  auto step = [&](auto refill_, int bi, Unit (&u)[T], int kb_refill) {
+    constexpr bool REFILL = decltype(refill_)::value != 0;
+    f16x8 xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[j] + bi * 1024);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      compute_unit(t, u[t], xf);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (REFILL) {
+        load_unit(t, kb_refill, u[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef W4A16_STAMPS
+    STAMP(2 + min(n_done, 7)); ++n_done;
+#endif
+  };
+
+  if (nblk > 0) {
+    // activations first: they come from L2 and are back before the weights
+    for (int bi = 0; bi < nblk; ++bi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + bi * 1024), 16, xlane,
+                                               (kb0 + bi * W) * 256, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    Unit u0[T], u1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) load_unit(t, kb0, u0[t]);
+    if constexpr (DB == 2) {
+      // (a wave with a single block fetches it twice: nothing in the prologue is conditional)
+      const int kb1 = nblk > 1 ? kb0 + W : kb0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) load_unit(t, kb1, u1[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    // everything but the DB * T units just requested has landed: the activations are in LDS
+    wait_vmcnt<DB * T * UL>();
+    if constexpr (DB == 1) {
+      int bi = 0;
+      for (; bi + 1 < nblk; ++bi) step(Flag<1>{}, bi, u0, kb0 + (bi + 1) * W);
+      step(Flag<0>{}, bi, u0, 0);
+    } else {
+      // u0 holds block bi, u1 block bi + 1; blocks that have a block two ahead go two per trip
+      int bi = 0;
+      for (; bi + 4 <= nblk; bi += 2) {
+        step(Flag<1>{}, bi, u0, kb0 + (bi + 2) * W);
+        step(Flag<1>{}, bi + 1, u1, kb0 + (bi + 3) * W);
+      }
+      const int rest = nblk - bi;
+      if (rest == 3) {
+        step(Flag<1>{}, bi, u0, kb0 + (bi + 2) * W);
+        step(Flag<0>{}, bi + 1, u1, 0);
+        step(Flag<0>{}, bi + 2, u0, 0);
+      } else {
+        step(Flag<0>{}, bi, u0, 0);
+        if (rest == 2) step(Flag<0>{}, bi + 1, u1, 0);
+      }
+    }
+  }
+  STAMP(10);
+
+  // Reduction over the waves: of a 16 x 16 partial tile only the lanes of tokens 0..3 (lane & 15 < 4) hold
+  // anything that is stored; they park their 16 bytes as [wave][tile][token][lane >> 4] and the first wave
+  // sums the W partials of every (tile, token, 4-column group), one lane each.
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + W * nb_max * 1024);
+  f32x4* const ws = e.ws;
+  unsigned* const tickets = e.tickets;
+  if (n16 < 4) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[((w * T + t) * 4 + n16) * 4 + kq] = acc[t];
+  }
+  __syncthreads();
+  STAMP(11);
+  if (w != 0) return;
+  const int ti = lane / 16, tok = (lane >> 2) & 3, grp = lane & 3;
+  const bool live = ti < H && tok < a.M;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, vu = v;
+  if (live) {
+    v = red[(ti * 4 + tok) * 4 + grp];
+#pragma unroll
+    for (int s = 1; s < W; ++s) v += red[((s * T + ti) * 4 + tok) * 4 + grp];
+    if constexpr (ACT) {
+      vu = red[((ti + H) * 4 + tok) * 4 + grp];
+#pragma unroll
+      for (int s = 1; s < W; ++s) vu += red[((s * T + ti + H) * 4 + tok) * 4 + grp];
+    }
+  }
+  const int S = gridDim.y;
+  if (S > 1) {
+    constexpr int SLOT = ACT ? 128 : 64;  // f32x4 per workgroup
+    const size_t slot = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+    // Partial sums and tickets travel as device-scope atomic accesses (each one coherent across the XCDs'
+    // L2s by itself), ordered by the wave's own completion counter: a device-scope fence would write back and
+    // invalidate a whole L2 per workgroup (~50 ns each, serialised: 69 us on a 1376-workgroup launch).
+    float* all = reinterpret_cast<float*>(ws + slot * S * SLOT);
+    auto put = [&](int idx, f32x4 r) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) __hip_atomic_store(all + idx * 4 + e, r[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto get = [&](int idx) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = __hip_atomic_load(all + idx * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return r;
+    };
+    put(blockIdx.y * SLOT + lane, v);
+    if constexpr (ACT) put(blockIdx.y * SLOT + 64 + lane, vu);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial sums have arrived before the ticket is drawn
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&tickets[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(S - 1)) return;  // whole wave
+    // last of the S workgroups of this output slot: the others' sums were complete before their tickets
+    v = get(lane);
+    for (int s = 1; s < S; ++s) v += get(s * SLOT + lane);
+    if constexpr (ACT) {
+      vu = get(64 + lane);
+      for (int s = 1; s < S; ++s) vu += get(s * SLOT + 64 + lane);
+    }
+    if (lane == 0) __hip_atomic_store(&tickets[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // as the next launch expects it
+  }
+  if (!live) return;
+  auto finish = [&](f32x4 r, int n_bias) {
+    f16x4 h = f16x4{(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w};
+    if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+    return h;
+  };
+  const int nt = nt0 + ti, n = nt * 16 + grp * 4;
+  if constexpr (ACT) {
+    const int NH = a.N / 2;
+    if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+  } else {
+    if (nt < a.NT && n < a.N) {
+      f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)tok * a.N + n);
+      f16x4 hv = finish(v, n);
+      if (a.add_out) hv = *dst + hv;
+      *dst = hv;
+    }
+  }
+  STAMP(12);
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // GEMM on the private layout, activations staged through LDS (M > 32)
 
@@ -555,12 +857,18 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
 // runs at a time then share their weight slices AND their activation rows through its L2, and every XCD gets
 // the same number of items whatever the slice count is (slices dealt out modulo 8 left up to a whole slice's
 // row blocks more on some XCDs: 36 workgroups against 24 on 32 CUs in bad cases).
-__device__ __forceinline__ bool map_workgroup(int n_slices, int m_blocks, int panel_rows, int& slice, int& mb) {
+__device__ __forceinline__ bool map_workgroup(int n_slices, int m_blocks, int panel_rows, int mb_magic, int& slice,
+                                              int& mb) {
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int total = n_slices * m_blocks;
   const int per = (total + 7) >> 3;
   const int j = xcd * per + idx;
   if (j >= total) return false;
+  if (mb_magic != 0) {  // one panel of m_blocks row blocks: no division
+    slice = (j * mb_magic) >> 16;
+    mb = j - slice * m_blocks;
+    return true;
+  }
   const int per_panel = panel_rows * n_slices;
   const int panel = j / per_panel, in_panel = j - panel * per_panel;
   const int rows_here = min(panel_rows, m_blocks - panel * panel_rows);
@@ -619,7 +927,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
   // an XCD runs at a time share their weight slices AND their activation rows through its L2.
   // Up to 8 row-blocks the panel is all of them: the row-blocks of a slice get ids 8 apart.
   int slice, mb;
-  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
   const int nt0 = (slice * HW + nw % HW) * T;
   const int m0 = mb * ROWS;
 
@@ -668,7 +976,7 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int s = 0; s < NSZ; ++s) {
-        const int g = min((kbe * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        const int g = min(group_of<SZS>(a, kbe * 128 + s * SZS * 32), a.NG - 1);
         b.sz[t][s] = szp[t][g * 16];
       }
     // Default cache policy: the row-blocks of a column slice run side by side on one XCD and the
@@ -875,17 +1183,6 @@ __global__ void __launch_bounds__(64 * NW * KW) gemm_tiled_kernel(int n_slices, 
 // half's k-steps to arrive.  No other wave touches that LDS, so the main loop has no barrier; the
 // DMA's completion is awaited with counted s_waitcnt vmcnt (vector-memory operations of a wave complete
 // in issue order; the compiler does not track data that arrives in LDS this way).
-template <int V>
-struct Flag {
-  static constexpr int value = V;
-};
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int MT, int T, int KW, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_blocks, int panel_rows,
                                                             const GemmArgs ga) {
@@ -916,7 +1213,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   // workgroup id -> (column slice, row block): row blocks of a slice share an XCD (ids 8 apart), in
   // panels once there are more than 8 of them (as gemm_tiled_kernel)
   int slice, mb;
-  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
   // A 32-column tile of the matrix instruction is two 16-column tiles of the packed layout: normally neighbours.
   // With the fused activation the weights are [gate | up] (N / 2 columns each, whole 16-column tiles) and tile
   // j of the workgroup is made of gate columns 16 j .. 16 j + 15 and the SAME columns of the up half, so that a
@@ -988,7 +1285,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int s = 0; s < NSZ; ++s) {
-        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
         b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
       }
 #pragma unroll
@@ -1253,7 +1550,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   const int r32 = lane & 31, h = lane >> 5;
 
   int slice, mb;
-  if (!map_workgroup(n_slices, m_blocks, panel_rows, slice, mb)) return;  // whole workgroup
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
   // fused activation: a tile is 16 gate columns and the same 16 columns of the up half (as in gemm_wide_kernel)
   const int ct0 = (slice * NW + w) * T;  // this wave's first tile
   const int m0 = mb * R;
@@ -1309,7 +1606,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int s = 0; s < NSZ; ++s) {
-        const int g = min((kb * 128 + s * SZS * 32) / a.G, a.NG - 1);
+        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
         b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
       }
 #pragma unroll
@@ -1792,6 +2089,10 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
   a->add_out = 0;
   a->mask = nullptr;
   a->x_bs = a->out_bs = a->pw_bs = a->psz_bs = a->bias_bs = 0;
+  a->batched = batch != 1;
+  // exact for every block index below 1024 and G / 128 <= 64: (kb * ceil(65536 / d)) >> 16 == kb / d
+  a->g_magic = (G % 128 == 0 && G / 128 <= 64 && a->KBS < 1024) ? (65536 + G / 128 - 1) / (G / 128) : 0;
+  a->mb_magic = 0;
   if (batch != 1) {
     if (batch < 1 || batch > 65535) return W4A16_E_SHAPE;
     // every problem's buffers must keep the alignment the kernels rely on
@@ -1807,6 +2108,12 @@ int fill_args(GemmArgs* a, const void* x, const void* packed_w, const void* pack
 }
 
 // The fused-activation variants are built for the row counts the streaming kernel serves by default.
+// j / m_blocks by multiply and shift for every work item j of a one-panel launch (exact while j * m_blocks < 65536)
+int row_block_magic(long long items, int m_blocks, int panel_rows) {
+  if (panel_rows != m_blocks || items * m_blocks >= 65536) return 0;
+  return (65536 + m_blocks - 1) / m_blocks;
+}
+
 template <int MT, int T>
 constexpr bool kActStreaming = (T % 2 == 0) && MT <= 2;
 
@@ -1888,7 +2195,9 @@ int launch_tiled(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   }
   // panels of W4A16_PANEL row-blocks once there are more than 8 of them (see the kernel's id mapping)
   const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
-  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW * KW), lds, s, n_slices, m_blocks, panel_rows, a);
+  GemmArgs am = a;
+  am.mb_magic = row_block_magic((long long)n_slices * m_blocks, m_blocks, panel_rows);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW * KW), lds, s, n_slices, m_blocks, panel_rows, am);
   return launched();
 }
 
@@ -1943,7 +2252,9 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act) {
     }
   }
   const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
-  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * KW), lds, s, n_slices, m_blocks, panel_rows, a);
+  GemmArgs am = a;
+  am.mb_magic = row_block_magic((long long)n_slices * m_blocks, m_blocks, panel_rows);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * KW), lds, s, n_slices, m_blocks, panel_rows, am);
   return launched();
 }
 
@@ -1993,7 +2304,9 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
     }
   }
   const int panel_rows = m_blocks > 8 ? W4A16_PANEL : m_blocks;
-  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW), lds, s, n_slices, m_blocks, panel_rows, a);
+  GemmArgs am = a;
+  am.mb_magic = row_block_magic((long long)n_slices * m_blocks, m_blocks, panel_rows);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW), lds, s, n_slices, m_blocks, panel_rows, am);
   return launched();
 }
 
@@ -2027,6 +2340,125 @@ int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, 
   return W4A16_E_SHAPE;
 }
 
+// ---- decode kernel (up to 4 rows) ----
+constexpr int kDecodeMaxRows = 4;
+constexpr int kMaxSplits = 8;
+
+// What the decode kernel's addressing admits: whole 128-k blocks, 32-bit byte offsets, and a group size whose
+// group index is a shift or one multiply away from the block index.
+bool decode_ok(const GemmArgs& a) {
+  if (a.M > kDecodeMaxRows || a.K % 128) return false;
+  if (!(a.G == 32 || a.G == 64 || (a.G % 128 == 0 && a.G / 128 <= 64))) return false;
+  if (a.KB >= 1024) return false;
+  if ((long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.NT * a.NG * 64 >= (1LL << 31)) return false;
+  return true;
+}
+
+// Bytes of workspace a K-split launch needs: one slot of fp32 partial sums per (problem, workgroup column,
+// split), then one ticket counter per (problem, workgroup column).
+size_t decode_partial_bytes(int batch, int gx, int splits, bool act) {
+  return (size_t)batch * gx * splits * (act ? 2048 : 1024);
+}
+// The ticket counters come first, in a region of fixed size: wherever a launch's partial sums land, they never
+// overwrite a counter that another launch shape expects to find at zero.
+constexpr int kMaxTickets = 16384;
+constexpr size_t kTicketBytes = (size_t)kMaxTickets * 4;
+size_t decode_ws_bytes(int batch, int gx, int splits, bool act) {
+  return splits <= 1 ? 0 : kTicketBytes + decode_partial_bytes(batch, gx, splits, act);
+}
+
+// scale/zero words per 128-k block and tile, and the LDS a workgroup needs: per wave 1 KiB of activations per
+// block, then the reduction's partial sums
+int decode_nsz(int G) { return G % 128 == 0 ? 1 : G == 64 ? 2 : 4; }
+size_t decode_lds_bytes(int t, int waves, int nb_max, int M, int G) {
+  (void)M, (void)G;
+  return (size_t)waves * nb_max * 1024 + (size_t)waves * t * 256;
+}
+
+template <int T, int W, int DB>
+int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
+  constexpr bool kPlain = T <= 4;
+  constexpr bool kAct = T % 2 == 0 && T / 2 <= 4;
+  if (!decode_ok(a) || (act && a.N % 32)) return W4A16_E_SHAPE;
+  if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
+  const int kb_per_split = ceil_div(a.KB, splits);
+  splits = ceil_div(a.KB, kb_per_split);  // no empty split
+  const int nb_max = ceil_div(kb_per_split, W);
+  const size_t lds = decode_lds_bytes(T, W, nb_max, a.M, a.G);
+  if (lds > 160 * 1024) return W4A16_E_SHAPE;
+  const int tiles = act ? a.NT / 2 : a.NT, per_wg = act ? T / 2 : T;
+  const int gx = ceil_div(tiles, per_wg);
+  f32x4* partial = nullptr;
+  unsigned* tickets = nullptr;
+  if (splits > 1) {
+    if (!ws) return W4A16_E_NULL;
+    if (misaligned(ws)) return W4A16_E_ALIGN;
+    if (ws_bytes < decode_ws_bytes(batch, gx, splits, act)) return W4A16_E_WORKSPACE;
+    if ((long long)batch * gx > kMaxTickets) return W4A16_E_SHAPE;
+    tickets = static_cast<unsigned*>(ws);
+    partial = reinterpret_cast<f32x4*>(static_cast<unsigned char*>(ws) + kTicketBytes);
+  }
+  DecodeArgs e;
+  e.ws = partial, e.tickets = tickets, e.kb_per_split = kb_per_split, e.nb_max = nb_max;
+  e.wstride = a.KBS * 1024, e.sstride = a.NG * 64;
+  void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
+  if (act) {
+    if constexpr (kAct) {
+      if (a.G % 128 == 0)
+        kern = gemm_decode_kernel<T, W, DB, 4, true>;
+      else if (a.G == 64)
+        kern = gemm_decode_kernel<T, W, DB, 2, true>;
+      else
+        kern = gemm_decode_kernel<T, W, DB, 1, true>;
+    }
+  } else {
+    if constexpr (kPlain) {
+      if (a.G % 128 == 0)
+        kern = gemm_decode_kernel<T, W, DB, 4>;
+      else if (a.G == 64)
+        kern = gemm_decode_kernel<T, W, DB, 2>;
+      else
+        kern = gemm_decode_kernel<T, W, DB, 1>;
+    }
+  }
+  if (!kern) return W4A16_E_SHAPE;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, splits, batch), dim3(64 * W), lds, s, a, e);
+  return launched();
+}
+
+// (t, waves) of the decode kernel; the fused activation takes the even t
+#define W4A16_FOR_EACH_DECODE(X) X(1, 16) X(2, 16) X(3, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8)
+
+// `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
+int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
+                    size_t ws_bytes, int depth = 0) {
+  if (depth == 0) depth = waves >= 16 ? W4A16_DECODE_DEPTH16 : 2;
+#define X(T_, W_)                                                                                     \
+  if (t == T_ && waves == W_)                                                                         \
+    return depth == 1 ? launch_decode<T_, W_, 1>(a, s, batch, act, splits, ws, ws_bytes)              \
+                      : launch_decode<T_, W_, 2>(a, s, batch, act, splits, ws, ws_bytes);
+  W4A16_FOR_EACH_DECODE(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
+bool decode_built(int t, int waves, bool act) {
+  if (act && t % 2) return false;
+#define X(T_, W_) \
+  if (t == T_ && waves == W_) return true;
+  W4A16_FOR_EACH_DECODE(X)
+#undef X
+  return false;
+}
+
 int pow2_floor(int v) {
   int p = 1;
   while (p * 2 <= v) p *= 2;
@@ -2044,6 +2476,7 @@ int pow2_floor(int v) {
 struct Choice {
   bool tiled;
   int mt, t, a, b;  // streaming: a = waves; tiled: a = nw, b = kw
+  int splits = 0;   // > 0: the decode kernel with t tiles, a waves and this many K splits
 };
 
 // Launch shape of the two 32x32x16 kernels: the built shape with the lowest estimated time,
@@ -2204,6 +2637,30 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   return best;
 }
 
+// The decode kernel takes over the streaming kernel's launches of up to 4 rows wherever it is built for the
+// shape chosen.  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
+// over K as well.
+Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool have_ws) {
+  Choice c = choose_cfg(M, K, N, batch, act);
+  if (c.tiled || c.mt != 1 || M > kDecodeMaxRows || !W4A16_DECODE) return c;
+  GemmArgs probe;
+  probe.M = M, probe.K = K, probe.N = N, probe.G = G;
+  probe.NT = ceil_div(N, 16), probe.KB = ceil_div(K, 128), probe.KBS = padded_kblocks(K), probe.NG = K / G;
+  if (!decode_ok(probe) || !decode_built(c.t, c.a, act)) return c;
+  const int per_wg = act ? c.t / 2 : c.t;
+  const int nb_max = ceil_div(probe.KB, c.a);
+  if (decode_lds_bytes(c.t, c.a, nb_max, M, G) > 160 * 1024) return c;
+  c.splits = 1;
+  if (have_ws) {
+    const long long wgs = (long long)ceil_div(act ? probe.NT / 2 : probe.NT, per_wg) * batch;
+    int sp = wgs > kMaxTickets ? 1 : (int)(256 / wgs);
+    if (sp > kMaxSplits) sp = kMaxSplits;
+    while (sp > 1 && probe.KB / sp < 2 * c.a) --sp;  // every wave keeps at least two blocks
+    if (sp > 1) c.splits = sp;
+  }
+  return c;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2219,6 +2676,7 @@ const char* w4a16_strerror(int code) {
     case W4A16_E_ALIGN: return "pointer is not 16-byte aligned";
     case W4A16_E_LAUNCH: return "HIP launch failed";
     case W4A16_E_TOO_LARGE: return "tensor too large for 32-bit indexing";
+    case W4A16_E_WORKSPACE: return "workspace too small";
     default: return "unknown w4a16 error";
   }
 }
@@ -2356,26 +2814,13 @@ int w4a16_gemm_packed_f16_wide_cfg(const void* x, const void* packed_w, const vo
   return dispatch_wide(a, mt, t, kw, static_cast<hipStream_t>(stream));
 }
 
-int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
-                          const void* bias, void* out, int M, int K, int N, int G, void* stream) {
-  if (M <= 0 || K <= 0 || N <= 0) return W4A16_E_SHAPE;
-  const Choice c = choose_cfg(M, K, N);
-  if (c.tiled && c.b < 0)  // 32x32x16 kernels: (mt, t, 1, -kw) private slabs, (mt, t, nw, -1) shared slab
-    return w4a16_gemm_packed_f16_wide_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t,
-                                          c.a > 1 ? -c.a : -c.b, stream);
-  if (c.tiled)
-    return w4a16_gemm_packed_f16_tiled_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t,
-                                           c.a, c.b, stream);
-  return w4a16_gemm_packed_f16_cfg(x, packed_w, packed_sz, bias, out, M, K, N, G, c.mt, c.t, c.a,
-                                   stream);
-}
-
 // Shared body of the batched / fused-epilogue entry points.  mt == 0: pick the launch shape.
 static int gemm_packed_general(const void* x, long long x_batch_stride, const void* packed_w,
                                const void* packed_sz, const void* bias, void* out,
                                long long out_batch_stride, int M, int K, int N, int G, int batch,
                                int epilogue, int mt, int t, int a_, int b_, void* stream,
-                               const void* problem_mask = nullptr, int active_hint = 0) {
+                               const void* problem_mask = nullptr, int active_hint = 0, void* ws = nullptr,
+                               size_t ws_bytes = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
   if (problem_mask && (reinterpret_cast<uintptr_t>(problem_mask) & 3u)) return W4A16_E_ALIGN;
   if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_SILU_MUL && epilogue != W4A16_EPI_ADD_TO_OUT)
@@ -2400,14 +2845,23 @@ static int gemm_packed_general(const void* x, long long x_batch_stride, const vo
   if (mt == 0) {
     // with a mask the launch shape is chosen for the problems expected to be on: the others cost nothing
     const int busy = (problem_mask && active_hint > 0 && active_hint < batch) ? active_hint : batch;
-    const Choice c = choose_cfg(M, K, N, busy, act);
+    const Choice c = choose_with_decode(M, K, N, G, busy, act, ws != nullptr);
     mt = c.mt, t = c.t, a_ = c.a, b_ = c.tiled ? c.b : 0;
+    if (c.splits > 0) mt = -1, b_ = c.splits;
   }
+  if (mt == -1)  // decode kernel: (t, waves, splits + 256 * depth)
+    return dispatch_decode(a, t, a_, s, batch, act, b_ & 255, ws, ws_bytes, b_ >> 8);
   if (b_ < 0) {  // 32x32x16 kernels: (mt, t, 1, -kw) private slabs, (mt, t, nw > 1, any b < 0) shared slab
     return a_ > 1 ? dispatch_wide_shared(a, mt, t, a_, s, batch, act) : dispatch_wide(a, mt, t, -b_, s, batch, act);
   }
   if (b_ > 0) return dispatch_tiled(a, mt, t, a_, b_, s, batch, act);
   return dispatch_packed(a, mt, t, a_, s, batch, act);
+}
+
+int w4a16_gemm_packed_f16(const void* x, const void* packed_w, const void* packed_sz,
+                          const void* bias, void* out, int M, int K, int N, int G, void* stream) {
+  return gemm_packed_general(x, 0, packed_w, packed_sz, bias, out, 0, M, K, N, G, 1, W4A16_EPI_NONE, 0, 0, 0, 0,
+                             stream);
 }
 
 int w4a16_gemm_packed_f16_batched_cfg(const void* x, long long x_batch_stride, const void* packed_w,
@@ -2445,12 +2899,60 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                              N, G, batch, epilogue, 0, 0, 0, 0, stream, problem_mask, active_hint);
 }
 
+int w4a16_gemm_packed_f16_decode_cfg(const void* x, long long x_batch_stride, const void* packed_w,
+                                     const void* packed_sz, const void* bias, void* out,
+                                     long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                     int epilogue, int t, int waves, int depth, int splits, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (t <= 0 || waves <= 0 || splits <= 0 || splits > kMaxSplits || depth < 0 || depth > 2) return W4A16_E_SHAPE;
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K, N, G,
+                             batch, epilogue, -1, t, waves, splits + 256 * depth, stream, nullptr, 0, workspace,
+                             workspace_bytes);
+}
+
+size_t w4a16_decode_workspace_bytes(int K, int N, int batch, int epilogue, int t, int waves, int splits) {
+  if (K <= 0 || N <= 0 || batch <= 0 || t <= 0 || waves <= 0 || splits <= 1 || splits > kMaxSplits) return 0;
+  const bool act = epilogue == W4A16_EPI_SILU_MUL;
+  const int KB = ceil_div(K, 128);
+  splits = ceil_div(KB, ceil_div(KB, splits));
+  const int NT = ceil_div(N, 16);
+  return decode_ws_bytes(batch, ceil_div(act ? NT / 2 : NT, act ? t / 2 : t), splits, act);
+}
+
+size_t w4a16_workspace_bytes(int M, int K, int N, int G, int batch, int epilogue) {
+  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0 || check_common(K, N, G)) return 0;
+  const bool act = epilogue == W4A16_EPI_SILU_MUL;
+  const Choice c = choose_with_decode(M, K, N, G, batch, act, true);
+  if (c.splits <= 1) return 0;
+  return w4a16_decode_workspace_bytes(K, N, batch, epilogue, c.t, c.a, c.splits);
+}
+
+int w4a16_gemm_packed_f16_ws(const void* x, long long x_batch_stride, const void* packed_w, const void* packed_sz,
+                             const void* bias, void* out, long long out_batch_stride, int M, int K, int N, int G,
+                             int batch, int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  // a workspace too small for the split the library would choose: the unsplit launch, not an error
+  if (workspace && workspace_bytes < w4a16_workspace_bytes(M, K, N, G, batch, epilogue)) workspace = nullptr;
+  return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K, N, G,
+                             batch, epilogue, 0, 0, 0, 0, stream, nullptr, 0, workspace, workspace_bytes);
+}
+
+int w4a16_launch_shape_ws(int M, int K, int N, int G, int batch, int epilogue, int shape[5]) {
+  if (!shape) return W4A16_E_NULL;
+  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0 || check_common(K, N, G)) return W4A16_E_SHAPE;
+  const Choice c = choose_with_decode(M, K, N, G, batch, epilogue == W4A16_EPI_SILU_MUL, true);
+  if (c.splits <= 0) return w4a16_launch_shape(M, K, N, batch, epilogue, shape);
+  shape[0] = W4A16_KERNEL_DECODE, shape[1] = 1, shape[2] = c.t, shape[3] = c.a, shape[4] = c.splits;
+  return W4A16_OK;
+}
+
 int w4a16_launch_shape(int M, int K, int N, int batch, int epilogue, int shape[5]) {
   if (!shape) return W4A16_E_NULL;
   if (M <= 0 || K <= 0 || N <= 0 || batch <= 0) return W4A16_E_SHAPE;
-  const Choice c = choose_cfg(M, K, N, batch, epilogue == W4A16_EPI_SILU_MUL);
+  const Choice c = choose_with_decode(M, K, N, 128, batch, epilogue == W4A16_EPI_SILU_MUL, false);
   shape[1] = c.mt, shape[2] = c.t;
-  if (!c.tiled) {
+  if (c.splits > 0) {
+    shape[0] = W4A16_KERNEL_DECODE, shape[3] = c.a, shape[4] = c.splits;
+  } else if (!c.tiled) {
     shape[0] = W4A16_KERNEL_STREAMING, shape[3] = c.a, shape[4] = 0;
   } else if (c.b > 0) {
     shape[0] = W4A16_KERNEL_LDS_STAGED, shape[3] = c.a, shape[4] = c.b;
@@ -2471,13 +2973,17 @@ int w4a16_built_shape(int kernel, int index, int shape[4]) {
   if (i++ == index) return shape[0] = A_, shape[1] = B_, shape[2] = C_, W4A16_OK;
 #define X4(A_, B_, C_, D_) \
   if (i++ == index) return shape[0] = A_, shape[1] = B_, shape[2] = C_, shape[3] = D_, W4A16_OK;
+#define X2(A_, B_) \
+  if (i++ == index) return shape[0] = A_, shape[1] = B_, W4A16_OK;
   switch (kernel) {
     case W4A16_KERNEL_STREAMING: W4A16_FOR_EACH_CFG(X3) break;
     case W4A16_KERNEL_LDS_STAGED: W4A16_FOR_EACH_TILED(X4) break;
     case W4A16_KERNEL_MFMA32: W4A16_FOR_EACH_WIDE(X3) break;
     case W4A16_KERNEL_MFMA32_SHARED: W4A16_FOR_EACH_WIDE_SHARED(X3) break;
+    case W4A16_KERNEL_DECODE: W4A16_FOR_EACH_DECODE(X2) break;
     default: break;
   }
+#undef X2
 #undef X3
 #undef X4
   return W4A16_E_SHAPE;
