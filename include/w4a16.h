@@ -254,6 +254,26 @@ int w4a16_gemm_packed_f16_ws(const void* x, long long x_batch_stride, const void
 int w4a16_launch_shape_ws(int M, int K, int N, int G, int batch, int epilogue, int shape[5]);
 
 /*
+ * w4a16_gemm_packed_f16_decode_cfg without the workspace arguments: the K-split launch runs on a device array of
+ * w4a16_static_scratch_bytes() bytes (1 MiB) that is part of the library's code object, so this entry point calls
+ * no allocator at all - neither hipMalloc / hipFree nor any routine that allocates.  No counterpart in the
+ * reference; it is for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  t == 0 takes the launch shape the library picks when it has a workspace (waves, depth
+ * and splits are then ignored; W4A16_E_SHAPE if the problem is not one for the decode kernel, i.e. more than 4
+ * rows or a shape it does not admit).  A launch that needs more than the array holds
+ * (w4a16_decode_workspace_bytes(...) > w4a16_static_scratch_bytes()) is refused with W4A16_E_WORKSPACE and
+ * nothing is enqueued.  Every GPU holds its own copy of the array until the process ends, and every call on a
+ * GPU shares that copy: the kernels return the counters they used to zero, so calls on one GPU may follow each
+ * other on any streams, but two that OVERLAP on one GPU race.  The current device must be the one that owns the
+ * buffers (the array's address is looked up, once per device, for the current device).
+ */
+size_t w4a16_static_scratch_bytes(void);
+int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride, const void* packed_w,
+                                        const void* packed_sz, const void* bias, void* out,
+                                        long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                        int epilogue, int t, int waves, int depth, int splits, void* stream);
+
+/*
  * Which kernel and launch shape w4a16_gemm_packed_f16 / _batched / _ex pick by themselves for a problem
  * (pure host arithmetic; for benchmarks, profiles and tests that need to name what ran).  No counterpart
  * in the reference, whose launch shape is fixed (gemm_kernels.cu:422-444).

@@ -140,7 +140,7 @@ def test_workspace_errors_and_sizes(L, ops, cuda):
     launch(L, cuda, tx, packed, K, N, G, 1, 8, 3, 1, None, expect=-5)    # depth is 0, 1 or 2
     x5 = dev_t(orc.make_inputs(5, K, N, G, seed=6)[0], cuda)
     launch(L, cuda, x5, packed, K, N, G, 1, 8, 0, 1, None, expect=-5)    # more than 4 rows
-    assert L.lib.w4a16_strerror(-9) == b"workspace too small"
+    assert L.lib.w4a16_strerror(-9).startswith(b"workspace too small")
     # splits beyond the k-blocks are trimmed, not an error: 8 blocks over "8 splits" of one block each
     ws = ops.gemm_workspace(cuda, L.lib.w4a16_decode_workspace_bytes(K, N, 1, 0, 1, 8, 8))
     y = launch(L, cuda, tx, packed, K, N, G, 1, 8, 0, 8, ws)

@@ -51,6 +51,9 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16_ws": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                  [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "w4a16_launch_shape_ws": (c_int, [c_int] * 6 + [ctypes.POINTER(c_int)]),
+    "w4a16_static_scratch_bytes": (c_size_t, []),
+    "w4a16_gemm_packed_f16_decode_static": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 +
+                                            [ctypes.c_longlong] + [c_int] * 10 + [c_void_p]),
     "w4a16_launch_shape": (c_int, [c_int] * 5 + [ctypes.POINTER(c_int)]),
     "w4a16_built_shape": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "w4a16_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),

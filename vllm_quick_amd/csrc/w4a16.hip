@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/w4a16.h"
 
 // Compile-time ablation switches for kernel experiments (scripts/); 0 in every shipped build.
@@ -2661,6 +2663,51 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   return c;
 }
 
+// ---- the library's own scratch, for callers that cannot hand in a workspace they allocated ----
+// K-split launches need ticket counters and room for partial sums (see gemm_decode_kernel).  This array is that
+// room for w4a16_gemm_packed_f16_decode_static: every GPU the library runs on holds its own copy, at its own
+// address, from the moment the code object is loaded until the process ends.  In host code the array's name is
+// only a handle for the runtime: the device address comes from hipGetSymbolAddress, once per device, and that
+// pointer is what the kernels get.
+constexpr size_t kStaticScratchBytes = (size_t)1 << 20;  // 64 KiB of counters + 960 KiB of partial sums
+}  // namespace (the symbol below has to be visible to HIP_SYMBOL)
+
+static __device__ __align__(256) unsigned char scratch[(size_t)1 << 20];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// The current device's copy of `scratch` (looked up and cleared on the first call on that device).
+int static_scratch(hipStream_t s, void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    g_last_hip_error = (int)e;
+    return W4A16_E_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ptr == nullptr) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+    // the counters must start at zero (the loader zero-fills the array; this covers a process that has
+    // already lost a launch half-way); afterwards the kernels themselves put every counter back
+    e = hipMemsetAsync(ptr, 0, kTicketBytes, s);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return W4A16_E_LAUNCH;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return W4A16_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2676,7 +2723,7 @@ const char* w4a16_strerror(int code) {
     case W4A16_E_ALIGN: return "pointer is not 16-byte aligned";
     case W4A16_E_LAUNCH: return "HIP launch failed";
     case W4A16_E_TOO_LARGE: return "tensor too large for 32-bit indexing";
-    case W4A16_E_WORKSPACE: return "workspace too small";
+    case W4A16_E_WORKSPACE: return "workspace too small (or the launch needs more than the library's own scratch)";
     default: return "unknown w4a16 error";
   }
 }
@@ -2934,6 +2981,32 @@ int w4a16_gemm_packed_f16_ws(const void* x, long long x_batch_stride, const void
   if (workspace && workspace_bytes < w4a16_workspace_bytes(M, K, N, G, batch, epilogue)) workspace = nullptr;
   return gemm_packed_general(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K, N, G,
                              batch, epilogue, 0, 0, 0, 0, stream, nullptr, 0, workspace, workspace_bytes);
+}
+
+size_t w4a16_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride, const void* packed_w,
+                                        const void* packed_sz, const void* bias, void* out,
+                                        long long out_batch_stride, int M, int K, int N, int G, int batch,
+                                        int epilogue, int t, int waves, int depth, int splits, void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || batch <= 0 || t < 0) return W4A16_E_SHAPE;
+  if (check_common(K, N, G)) return check_common(K, N, G);
+  if (t == 0) {  // the library's choice, as w4a16_gemm_packed_f16_ws makes it with a workspace
+    const Choice c = choose_with_decode(M, K, N, G, batch, epilogue == W4A16_EPI_SILU_MUL, true);
+    if (c.splits <= 0) return W4A16_E_SHAPE;  // not a decode-kernel problem: nothing here needs scratch
+    t = c.t, waves = c.a, depth = 0, splits = c.splits;
+  }
+  // the size is checked against the array before anything else is done with it
+  if (w4a16_decode_workspace_bytes(K, N, batch, epilogue, t, waves, splits) > kStaticScratchBytes)
+    return W4A16_E_WORKSPACE;
+  void* ptr = nullptr;
+  if (splits > 1) {
+    const int rc = static_scratch(static_cast<hipStream_t>(stream), &ptr);
+    if (rc) return rc;
+  }
+  return w4a16_gemm_packed_f16_decode_cfg(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
+                                          N, G, batch, epilogue, t, waves, depth, splits, ptr, kStaticScratchBytes,
+                                          stream);
 }
 
 int w4a16_launch_shape_ws(int M, int K, int N, int G, int batch, int epilogue, int shape[5]) {
