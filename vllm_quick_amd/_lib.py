@@ -95,7 +95,7 @@ def launch_shape(M: int, K: int, N: int, batch: int = 1, epilogue: int = 0) -> s
     buf = (c_int * 5)()
     check(lib.w4a16_launch_shape(M, K, N, batch, epilogue, buf), "launch_shape")
     kind, mt, t, a, b = list(buf)
-    args = {0: (mt, t, a), 1: (mt, t, a, b), 2: (mt, t, b), 3: (mt, t, a)}[kind]
+    args = {0: (mt, t, a), 1: (mt, t, a, b), 2: (mt, t, b), 3: (mt, t, a), 4: (t, a)}[kind]
     return f"{KERNEL_NAMES[kind]}<{','.join(str(v) for v in args)}>"
 
 

@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "../../include/w4a16.h"
@@ -67,6 +69,9 @@
 #endif
 #ifndef W4A16_DECODE_DEPTH16
 #define W4A16_DECODE_DEPTH16 1  // blocks in flight per wave of a 16-wave decode workgroup
+#endif
+#ifndef W4A16_DECODE_STEAL
+#define W4A16_DECODE_STEAL 1
 #endif
 #ifndef W4A16_ILV
 #define W4A16_ILV 1  // the 32x32x16 kernel deals matrix and conversion instructions out alternately
@@ -610,13 +615,15 @@ struct DecodeArgs {
   int nb_max;         // most blocks any wave takes
   int wstride;        // bytes of one column tile in packed_w
   int sstride;        // bytes of one column tile in packed_sz
+  int steal;          // the oldest quarter of the waves takes one block each from the youngest quarter
 };
 
 template <int T, int W, int DB, int SZS, bool ACT = false>
 __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
   fetch_args_now(ga);
-  asm volatile("" ::"s"(e.ws), "s"(e.tickets), "s"(e.kb_per_split), "s"(e.nb_max), "s"(e.wstride), "s"(e.sstride));
+  asm volatile("" ::"s"(e.ws), "s"(e.tickets), "s"(e.kb_per_split), "s"(e.nb_max), "s"(e.wstride), "s"(e.sstride),
+               "s"(e.steal));
   if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
   const GemmArgs a = batch_slice(ga);
   constexpr int NSZ = 4 / SZS;             // scale/zero words per 128-k block and tile
@@ -644,7 +651,23 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   const int kb_lo = blockIdx.y * e.kb_per_split;
   const int kb_hi = min(kb_lo + e.kb_per_split, a.KB);
   const int kb0 = kb_lo + w;
-  const int nblk = kb0 < kb_hi ? (kb_hi - kb0 + W - 1) / W : 0;
+  const int own = kb0 < kb_hi ? (kb_hi - kb0 + W - 1) / W : 0;  // blocks kb0, kb0 + W, ..
+  // Requests are admitted oldest wave first, so the youngest quarter of the waves gets its data last and would
+  // finish last.  Where every wave has at least two blocks, each wave of that quarter hands its last block to
+  // the wave three quarters of a workgroup older, which has long been waiting by then.
+  int nblk = own, kb_extra = 0;
+  if (W4A16_DECODE_STEAL && e.steal) {
+    constexpr int Q = W / 4;
+    if (w >= 3 * Q) {
+      nblk = own - 1;
+    } else if (w < Q) {
+      const int young = kb0 + 3 * Q;  // first block of the wave this one takes a block from
+      const int young_own = young < kb_hi ? (kb_hi - young + W - 1) / W : 0;
+      kb_extra = young + (young_own - 1) * W;
+      nblk = own + 1;
+    }
+  }
+  auto kb_of = [&](int bi) { return bi < own ? kb0 + bi * W : kb_extra; };
 
   const __amdgpu_buffer_rsrc_t w_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, a.NT * e.wstride, 0x00020000);
@@ -728,14 +751,14 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     // activations first: they come from L2 and are back before the weights
     for (int bi = 0; bi < nblk; ++bi)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + bi * 1024), 16, xlane,
-                                               (kb0 + bi * W) * 256, 0, 0);
+                                               kb_of(bi) * 256, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     Unit u0[T], u1[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) load_unit(t, kb0, u0[t]);
     if constexpr (DB == 2) {
       // (a wave with a single block fetches it twice: nothing in the prologue is conditional)
-      const int kb1 = nblk > 1 ? kb0 + W : kb0;
+      const int kb1 = nblk > 1 ? kb_of(1) : kb0;
 #pragma unroll
       for (int t = 0; t < T; ++t) load_unit(t, kb1, u1[t]);
     }
@@ -745,18 +768,18 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     wait_vmcnt<DB * T * UL>();
     if constexpr (DB == 1) {
       int bi = 0;
-      for (; bi + 1 < nblk; ++bi) step(Flag<1>{}, bi, u0, kb0 + (bi + 1) * W);
+      for (; bi + 1 < nblk; ++bi) step(Flag<1>{}, bi, u0, kb_of(bi + 1));
       step(Flag<0>{}, bi, u0, 0);
     } else {
       // u0 holds block bi, u1 block bi + 1; blocks that have a block two ahead go two per trip
       int bi = 0;
       for (; bi + 4 <= nblk; bi += 2) {
-        step(Flag<1>{}, bi, u0, kb0 + (bi + 2) * W);
-        step(Flag<1>{}, bi + 1, u1, kb0 + (bi + 3) * W);
+        step(Flag<1>{}, bi, u0, kb_of(bi + 2));
+        step(Flag<1>{}, bi + 1, u1, kb_of(bi + 3));
       }
       const int rest = nblk - bi;
       if (rest == 3) {
-        step(Flag<1>{}, bi, u0, kb0 + (bi + 2) * W);
+        step(Flag<1>{}, bi, u0, kb_of(bi + 2));
         step(Flag<0>{}, bi + 1, u1, 0);
         step(Flag<0>{}, bi + 2, u0, 0);
       } else {
@@ -2377,6 +2400,12 @@ size_t decode_lds_bytes(int t, int waves, int nb_max, int M, int G) {
   return (size_t)waves * nb_max * 1024 + (size_t)waves * t * 256;
 }
 
+// Developer switch (W4A16_NO_STEAL=1 in the environment): the plain round-robin split of K over the waves.
+bool depth_steal_env() {
+  static const bool on = getenv("W4A16_NO_STEAL") == nullptr;
+  return on;
+}
+
 template <int T, int W, int DB>
 int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
   constexpr bool kPlain = T <= 4;
@@ -2386,7 +2415,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   const int kb_per_split = ceil_div(a.KB, splits);
   splits = ceil_div(a.KB, kb_per_split);  // no empty split
   const int nb_max = ceil_div(kb_per_split, W);
-  const size_t lds = decode_lds_bytes(T, W, nb_max, a.M, a.G);
+  const size_t lds = decode_lds_bytes(T, W, nb_max + 1, a.M, a.G);  // (+ 1: a wave may take a block from another)
   if (lds > 160 * 1024) return W4A16_E_SHAPE;
   const int tiles = act ? a.NT / 2 : a.NT, per_wg = act ? T / 2 : T;
   const int gx = ceil_div(tiles, per_wg);
@@ -2401,8 +2430,11 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
     partial = reinterpret_cast<f32x4*>(static_cast<unsigned char*>(ws) + kTicketBytes);
   }
   DecodeArgs e;
-  e.ws = partial, e.tickets = tickets, e.kb_per_split = kb_per_split, e.nb_max = nb_max;
+  e.ws = partial, e.tickets = tickets, e.kb_per_split = kb_per_split, e.nb_max = nb_max + 1;
   e.wstride = a.KBS * 1024, e.sstride = a.NG * 64;
+  // every wave of every split must own at least two blocks (the shortest split is the last one)
+  const int last_split = a.KB - (splits - 1) * kb_per_split;
+  e.steal = (W >= 8 && last_split >= 2 * W && depth_steal_env()) ? 1 : 0;
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
   if (act) {
     if constexpr (kAct) {
@@ -2651,7 +2683,7 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   if (!decode_ok(probe) || !decode_built(c.t, c.a, act)) return c;
   const int per_wg = act ? c.t / 2 : c.t;
   const int nb_max = ceil_div(probe.KB, c.a);
-  if (decode_lds_bytes(c.t, c.a, nb_max, M, G) > 160 * 1024) return c;
+  if (decode_lds_bytes(c.t, c.a, nb_max + 1, M, G) > 160 * 1024) return c;
   c.splits = 1;
   if (have_ws) {
     const long long wgs = (long long)ceil_div(act ? probe.NT / 2 : probe.NT, per_wg) * batch;
