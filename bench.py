@@ -29,6 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -513,6 +514,31 @@ def main():
                 "algorithmic_bytes": algorithmic_bytes(1, K, N, G),
                 "launch_us": m1["us"],
             }
+            # K split over workgroups on a layer with a long K and too few columns to fill the chip (1 row): the
+            # plain launch, the launch with a caller workspace, and the entry point that runs on the library's
+            # own device array
+            Ks, Ns = 14336, 512
+            narrow = [ops.awq_repack(*make_weights(Ks, Ns, G, seed=50 + i, device=device)) for i in range(NBUF)]
+            x1 = make_x(1, Ks, seed=9, device=device)
+            ws = ops.gemm_workspace(device, 1 << 20)
+            o1 = torch.empty((1, Ns), dtype=torch.float16, device=device)
+
+            def static_call(pk):
+                check(lib.w4a16_gemm_packed_f16_decode_static(
+                    x1.data_ptr(), 0, pk.packed_w.data_ptr(), pk.packed_sz.data_ptr(), None, o1.data_ptr(), 0, 1, Ks,
+                    Ns, G, 1, 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream), "decode_static")
+            shape_ws = (ctypes.c_int * 5)()
+            check(lib.w4a16_launch_shape_ws(1, Ks, Ns, G, 1, 0, shape_ws), "launch_shape_ws")
+            out["split_k"] = {
+                "layer": f"{Ks}x{Ns}, 1 row", "kernel": launch_shape(1, Ks, Ns), "splits_with_workspace": shape_ws[4],
+                "plain_us": time_launches([(lambda pk=pk: ops.awq_gemm_packed(x1, pk)) for pk in narrow], stream,
+                                          launches, args.warmup),
+                "workspace_us": time_launches([(lambda pk=pk: ops.awq_gemm_packed(x1, pk, workspace=ws))
+                                               for pk in narrow], stream, launches, args.warmup),
+                "static_scratch_us": time_launches([(lambda pk=pk: static_call(pk)) for pk in narrow], stream,
+                                                   launches, args.warmup),
+            }
+            del narrow
             # context: the dense fp16 GEMM torch dispatches to (hipBLASLt) on the same shape
             wd = torch.randn((K, N), device=device).half()
             us = time_launches([(lambda: torch.matmul(x_full, wd))] * 4, stream, 64, 8)

@@ -218,13 +218,14 @@ def test_library_choice_with_a_workspace(L, ops, cuda):
     """A narrow layer with a long K at a few rows is split over K once a workspace is there, served by the decode
     kernel without one; both within tolerance, the default entry points unchanged."""
     import ctypes
-    K, N, G = 8192, 1280, 128
+    K, N, G = 14336, 512, 128
     buf = (ctypes.c_int * 5)()
-    assert L.lib.w4a16_launch_shape(1, K, N, 1, 0, buf) == 0 and list(buf) == [4, 1, 1, 16, 1]
-    assert L.lib.w4a16_launch_shape_ws(1, K, N, G, 1, 0, buf) == 0 and buf[0] == 4 and buf[4] > 1
+    assert L.lib.w4a16_launch_shape(1, K, N, 1, 0, buf) == 0 and buf[0] == 4 and buf[4] == 1
+    assert L.lib.w4a16_launch_shape_ws(1, K, N, G, 1, 0, buf) == 0 and buf[0] == 4 and buf[4] == 3
     assert L.lib.w4a16_launch_shape_ws(64, K, N, G, 1, 0, buf) == 0 and buf[0] != 4
     assert L.lib.w4a16_workspace_bytes(1, K, N, G, 1, 0) > 65536
     assert L.lib.w4a16_workspace_bytes(1, 4096, 11008, G, 1, 0) == 0   # enough column tiles: no split
+    assert L.lib.w4a16_workspace_bytes(1, 8192, 1280, G, 1, 0) == 0    # K too short for a split to pay
     assert L.lib.w4a16_workspace_bytes(64, K, N, G, 1, 0) == 0
     ws = ops.gemm_workspace(cuda)
     for M in (1, 4):
@@ -268,3 +269,26 @@ def test_split_launch_replays_from_a_graph(L, ops, cuda):
         g.replay()
         torch.cuda.synchronize()
     assert_parity(out.cpu().numpy(), orc.gemm_faithful(x2, qw, s, qz), orc.gemm_exact(x2, qw, s, qz), "replay")
+
+
+def test_linear_method_split_k_option(ops, cuda):
+    """AWQLinearMethod(split_k=True) routes up to 4 tokens through the stream's workspace; same results within the
+    tolerance, more rows and the default method untouched."""
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    from vllm_quick_amd.layers.quantization.awq import AWQLinearMethod
+    K, N, G = 14336, 512, 128
+    cfg = AWQConfig(4, G, True)
+    plain, split = AWQLinearMethod(cfg), AWQLinearMethod(cfg, split_k=True)
+    for M in (1, 4, 9):
+        x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=31 + M)
+        weights = {"qweight": dev_t(qw, cuda), "scales": dev_t(s, cuda), "qzeros": dev_t(qz, cuda)}
+        tx = dev_t(x, cuda)
+        y0, y1 = plain.apply_weights(weights, tx), split.apply_weights(dict(weights), tx)
+        if M > 4:
+            assert torch.equal(y0, y1)
+        else:
+            ulps = 2.0**-9 * y0.float().abs() + 1e-6
+            assert ((y0.float() - y1.float()).abs() <= ulps).all()
+    ws = ops.stream_workspace(cuda)
+    assert ws is not None and ws.numel() == 1 << 20 and ops.stream_workspace(cuda) is ws
+    assert int(ws[:65536].view(torch.int32).abs().max().item()) == 0

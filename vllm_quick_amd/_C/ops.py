@@ -129,6 +129,24 @@ def gemm_workspace(device: torch.device, nbytes: int = 4 << 20) -> torch.Tensor:
     return torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_STREAM_WORKSPACES: dict = {}
+
+
+def stream_workspace(device: torch.device) -> Optional[torch.Tensor]:
+    """The workspace of torch's current stream on `device` (made on first use, 1 MiB): launches on one stream
+    follow each other, so they can share one; another stream gets its own.  None while a graph is being captured
+    and the stream has none yet (allocating and zeroing inside a capture is not wanted): the call then runs
+    without a split."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    ws = _STREAM_WORKSPACES.get(key)
+    if ws is None:
+        if stream_is_capturing():
+            return None
+        ws = _STREAM_WORKSPACES[key] = gemm_workspace(torch.device("cuda", idx), 1 << 20)
+    return ws
+
+
 def _check_workspace(workspace: torch.Tensor, device: torch.device) -> None:
     if not workspace.is_cuda or workspace.device != device or not workspace.is_contiguous():
         raise RuntimeError("workspace must be a contiguous tensor on the device of the activations")

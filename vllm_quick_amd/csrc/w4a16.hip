@@ -67,9 +67,6 @@
 #ifndef W4A16_DECODE
 #define W4A16_DECODE 1  // the decode kernel serves up to 4 rows by default
 #endif
-#ifndef W4A16_DECODE_DEPTH16
-#define W4A16_DECODE_DEPTH16 1  // blocks in flight per wave of a 16-wave decode workgroup
-#endif
 #ifndef W4A16_DECODE_STEAL
 #define W4A16_DECODE_STEAL 1
 #endif
@@ -2474,7 +2471,11 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
                     size_t ws_bytes, int depth = 0) {
-  if (depth == 0) depth = waves >= 16 ? W4A16_DECODE_DEPTH16 : 2;
+  // Two blocks in flight per wave wherever that keeps a workgroup within ~64 KiB of outstanding weights (a CU
+  // takes no more than that in at a time: beyond it the youngest waves' first requests wait for the oldest waves'
+  // second blocks): 8192 x 1280 at 1 row 5.2 us against 5.8 with one block, 11008 x 4096 7.0 against 7.9,
+  // 8192 x 3584 5.6 against 6.9; the 3-tile 16-wave shape (4096 x 11008) stays at one block, 7.0 against 7.4.
+  if (depth == 0) depth = t * waves <= 32 ? 2 : 1;
 #define X(T_, W_)                                                                                     \
   if (t == T_ && waves == W_)                                                                         \
     return depth == 1 ? launch_decode<T_, W_, 1>(a, s, batch, act, splits, ws, ws_bytes)              \
@@ -2686,11 +2687,17 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   if (decode_lds_bytes(c.t, c.a, nb_max + 1, M, G) > 160 * 1024) return c;
   c.splits = 1;
   if (have_ws) {
+    // A split pays where a wave's chain of blocks is long (its requests go out a block or two at a time, a
+    // memory latency each) and the workgroups are few: from K = 12800 on, about 40 blocks per split
+    // (14336 x 512 at 1 row 7.4 -> 6.0 us with 3 splits, 16384 x 1024 8.1 -> 6.7; at K = 11008 it is a wash and
+    // at K <= 8192 the exchange through memory costs more than it saves).
     const long long wgs = (long long)ceil_div(act ? probe.NT / 2 : probe.NT, per_wg) * batch;
-    int sp = wgs > kMaxTickets ? 1 : (int)(256 / wgs);
-    if (sp > kMaxSplits) sp = kMaxSplits;
-    while (sp > 1 && probe.KB / sp < 2 * c.a) --sp;  // every wave keeps at least two blocks
-    if (sp > 1) c.splits = sp;
+    if (probe.KB >= 100 && wgs <= 128) {
+      int sp = (probe.KB + 20) / 40;
+      if (sp > 256 / wgs) sp = (int)(256 / wgs);
+      if (sp > kMaxSplits) sp = kMaxSplits;
+      if (sp > 1) c.splits = sp;
+    }
   }
   return c;
 }

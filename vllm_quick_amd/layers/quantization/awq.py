@@ -85,16 +85,24 @@ class AWQLinearMethod(LinearMethodBase):
         keep_stock: `False` lets `drop_stock()` release a layer's stock tensors once they have been
             re-ordered into the private layout (the reference's GPTQ path re-orders its weights in place
             on first use in the same spirit, gptq.py:197-204); otherwise both copies stay resident.
+        split_k: up to 4 tokens, let the library split K over workgroups where a layer has too few
+            columns to fill the chip (a tensor-parallel rank's qkv projection), through one workspace per
+            stream (`ops.stream_workspace`).  The reference always splits K eight ways through a
+            [split_k, M, N] tensor (gemm_kernels.cu:420-445).  Off by default: launches that share a
+            workspace must not overlap, which holds for everything enqueued on one stream but is the
+            caller's business once graphs captured on one stream are replayed on several.
     """
 
     REFERENCE_FP16_MATMUL_THRESHOLD = 256
     DEFAULT_FP16_MATMUL_THRESHOLD = None
 
     def __init__(self, quant_config: AWQConfig,
-                 fp16_matmul_threshold: Optional[int] = DEFAULT_FP16_MATMUL_THRESHOLD, keep_stock: bool = True):
+                 fp16_matmul_threshold: Optional[int] = DEFAULT_FP16_MATMUL_THRESHOLD, keep_stock: bool = True,
+                 split_k: bool = False):
         self.quant_config = quant_config
         self.fp16_matmul_threshold = fp16_matmul_threshold
         self.keep_stock = keep_stock
+        self.split_k = split_k
 
     def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
                        output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
@@ -179,7 +187,11 @@ class AWQLinearMethod(LinearMethodBase):
             if bias is not None:
                 out = out + bias
         else:
-            out = ops.awq_gemm_packed(reshaped_x, packed, bias=bias)
+            if self.split_k and num_tokens <= 4:
+                out = ops.awq_gemm_packed(reshaped_x, packed, bias=bias,
+                                          workspace=ops.stream_workspace(reshaped_x.device))
+            else:
+                out = ops.awq_gemm_packed(reshaped_x, packed, bias=bias)
         return out.reshape(out_shape)
 
     def apply_weights_silu_and_mul(self, weights: Dict[str, Any], x: torch.Tensor,
