@@ -220,7 +220,7 @@ def test_library_choice_with_a_workspace(L, ops, cuda):
     import ctypes
     K, N, G = 14336, 512, 128
     buf = (ctypes.c_int * 5)()
-    assert L.lib.w4a16_launch_shape(1, K, N, 1, 0, buf) == 0 and buf[0] == 4 and buf[4] == 1
+    assert L.lib.w4a16_launch_shape(1, K, N, 1, 0, buf) == 0 and list(buf) == [4, 1, 1, 16, 1]
     assert L.lib.w4a16_launch_shape_ws(1, K, N, G, 1, 0, buf) == 0 and buf[0] == 4 and buf[4] == 3
     assert L.lib.w4a16_launch_shape_ws(64, K, N, G, 1, 0, buf) == 0 and buf[0] != 4
     assert L.lib.w4a16_workspace_bytes(1, K, N, G, 1, 0) > 65536

@@ -2681,7 +2681,15 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   GemmArgs probe;
   probe.M = M, probe.K = K, probe.N = N, probe.G = G;
   probe.NT = ceil_div(N, 16), probe.KB = ceil_div(K, 128), probe.KBS = padded_kblocks(K), probe.NG = K / G;
-  if (!decode_ok(probe) || !decode_built(c.t, c.a, act)) return c;
+  if (!decode_ok(probe)) return c;
+  // One or two rows over a very long K: the streaming kernel prefers 8 waves there, the decode kernel 16 with two
+  // blocks each in flight (14336 x 4096 at 1 row 8.6 us against 9.9 with 8 waves and 10.2 for the streaming kernel).
+  const long long col_tiles = (long long)(act ? probe.NT / 2 : probe.NT) * batch;
+  if (!act && c.a == 8 && M <= 2 && probe.KB >= 100 && col_tiles <= 3 * 256) {
+    const int t16 = (int)(col_tiles <= 256 ? 1 : col_tiles <= 512 ? 2 : 3);
+    if (decode_lds_bytes(t16, 16, ceil_div(probe.KB, 16) + 1, M, G) <= 160 * 1024) c.t = t16, c.a = 16;
+  }
+  if (!decode_built(c.t, c.a, act)) return c;
   const int per_wg = act ? c.t / 2 : c.t;
   const int nb_max = ceil_div(probe.KB, c.a);
   if (decode_lds_bytes(c.t, c.a, nb_max + 1, M, G) > 160 * 1024) return c;
