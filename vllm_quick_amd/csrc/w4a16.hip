@@ -613,6 +613,8 @@ struct DecodeArgs {
   int wstride;        // bytes of one column tile in packed_w
   int sstride;        // bytes of one column tile in packed_sz
   int steal;          // the oldest quarter of the waves takes one block each from the youngest quarter
+  int splits;         // workgroups per output slot (gridDim.y; here so that nobody fetches it at the very end)
+  int gx;             // workgroup columns (gridDim.x)
 };
 
 template <int T, int W, int DB, int SZS, bool ACT = false>
@@ -620,7 +622,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
   fetch_args_now(ga);
   asm volatile("" ::"s"(e.ws), "s"(e.tickets), "s"(e.kb_per_split), "s"(e.nb_max), "s"(e.wstride), "s"(e.sstride),
-               "s"(e.steal));
+               "s"(e.steal), "s"(e.splits), "s"(e.gx));
   if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
   const GemmArgs a = batch_slice(ga);
   constexpr int NSZ = 4 / SZS;             // scale/zero words per 128-k block and tile
@@ -813,10 +815,10 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       for (int s = 1; s < W; ++s) vu += red[((s * T + ti + H) * 4 + tok) * 4 + grp];
     }
   }
-  const int S = gridDim.y;
+  const int S = e.splits;
   if (S > 1) {
     constexpr int SLOT = ACT ? 128 : 64;  // f32x4 per workgroup
-    const size_t slot = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+    const size_t slot = (size_t)blockIdx.z * e.gx + blockIdx.x;
     // Partial sums and tickets travel as device-scope atomic accesses (each one coherent across the XCDs'
     // L2s by itself), ordered by the wave's own completion counter: a device-scope fence would write back and
     // invalidate a whole L2 per workgroup (~50 ns each, serialised: 69 us on a 1376-workgroup launch).
@@ -2432,6 +2434,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   // every wave of every split must own at least two blocks (the shortest split is the last one)
   const int last_split = a.KB - (splits - 1) * kb_per_split;
   e.steal = (W >= 8 && last_split >= 2 * W && depth_steal_env()) ? 1 : 0;
+  e.splits = splits, e.gx = gx;
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
   if (act) {
     if constexpr (kAct) {
