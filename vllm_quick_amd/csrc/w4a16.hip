@@ -12,23 +12,29 @@
 // small, and each lane ends up holding 4 adjacent output columns of one
 // token, which store as 8 contiguous bytes).
 //
-// Two GEMM kernels share that layout and the bit-exact register conversion
+// The GEMM kernels share that layout and the bit-exact register conversion
 // (fp16((q - z) * s), as the reference computes it):
 //
+//  * gemm_decode_kernel (up to 4 rows): weights in 1-KiB units paced one or two
+//    128-k blocks ahead per wave, activations staged once per wave in private LDS,
+//    optionally K split over workgroups through a workspace (see its comment).
 //  * gemm_packed_kernel ("streaming", up to 32 rows): a workgroup owns T column
 //    tiles x MT row tiles of the output over the WHOLE of K; its W wavefronts
 //    split K between them (wave w takes 128-k blocks w, w+W, ...), stream their
 //    weight blocks HBM -> VGPR with 16-byte loads, read the activation fragments
 //    straight from L2, and combine their fp32 partial tiles through LDS at the end.
-//  * gemm_tiled_kernel ("LDS-staged", more rows): the same K split, but the
-//    activation slab of each 128-k block is fetched once per workgroup in whole
-//    cache lines and shared through swizzled LDS by the waves that split the
-//    workgroup's columns.
+//  * gemm_tiled_kernel ("LDS-staged"): the same K split, but the activation slab
+//    of each 128-k block is fetched once per workgroup in whole cache lines and
+//    shared through swizzled LDS by the waves that split the workgroup's columns.
+//  * gemm_wide_kernel / gemm_wide_shared_kernel (v_mfma_f32_32x32x16_f16, more
+//    rows): activation slabs by LDS-DMA, private per wave with a K split, or one
+//    per workgroup without.
+//  * gemm_stock_kernel: the same arithmetic straight on the stock tensors.
 //
-// Both take a batch of same-shaped problems in one launch (blockIdx.z) and an
-// optional fused silu(gate) * up epilogue for merged gate/up weights.  There is
-// no cross-workgroup split-K, hence no workspace, no atomics and a result that
-// does not depend on dispatch order.
+// All of them take a batch of same-shaped problems in one launch (blockIdx.z);
+// all but the last an optional fused silu(gate) * up epilogue for merged gate/up
+// weights.  Only the decode kernel's K split goes across workgroups; its partial
+// sums are added in split order, so no result depends on dispatch order.
 //
 // Reference behaviour replaced: csrc/quantization/awq/gemm_kernels.cu:30-272
 // (GEMM), :274-381 (dequantize), csrc/quantization/awq/dequantize.cuh:17-84.
@@ -585,19 +591,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ---------------------------------------------------------------------------
 // Decode GEMM on the private layout: up to 4 rows, paced weight stream, optional K split over workgroups
 // ---------------------------------------------------------------------------
-// The streaming kernel above requests everything a wave will ever need at once, activations and scale/zero
-// words included, in fragment-shaped loads: at one row a wave of the 4096 x 11008 launch issues 20 vector-memory
-// instructions for 6 KiB of weights, a CU holds only so many bytes in flight (about 50-60 KiB), and requests
-// are admitted oldest wave first, so the youngest waves of a workgroup get theirs in thousands of cycles after
-// the oldest, receive their data last and still have all of their arithmetic to do after the last byte.
+// The streaming kernel above requests everything a wave will ever need at once, activations included, in
+// fragment-shaped loads: at one row a wave of the 4096 x 11008 launch issues 20 vector-memory instructions for
+// 6 KiB of weights.  A CU holds only so many bytes in flight (about 50-60 KiB) and admits requests oldest wave
+// first, so the youngest waves of a workgroup get theirs in thousands of cycles after the oldest, receive their
+// data last and still have all of their arithmetic to do after the last byte.
 //
-// Here only the weights travel through registers.  A wave's activations (its k-blocks x up to 4 rows x 256
-// bytes) and its scale/zero words (64 bytes per tile and group) go to a private piece of LDS by LDS-DMA once,
-// ahead of the weights, in one or two instructions with only the lanes that carry something switched on, and
-// come back as ds_read_b128 B fragments and ds_read_b32 constants.  Chunk c of activation row r sits at
-// 16-byte position c ^ 4r of the row's 256 bytes, so the rows a fragment read touches fall into different banks.
-// The weights come in units of 1 KiB (one tile's 128-k block, one instruction); a wave keeps DB blocks of T
-// units in flight and asks for the unit DB blocks ahead as soon as it has consumed a unit.
+// Here a wave's activations (its k-blocks x up to 4 rows x 256 bytes) go to a private piece of LDS once, ahead
+// of the weights, by one LDS-DMA instruction per block (rows past M - 1 repeat the last row), and come back as
+// ds_read_b128 B fragments: chunk c of activation row r sits at 16-byte position c ^ 4r of the row's 256
+// bytes, so the rows a fragment read touches fall into different banks.  The weights come in units of 1 KiB
+// (one tile's 128-k block, one instruction, with the tile's scale/zero word(s) for the block); a wave keeps DB
+// blocks of T units in flight and asks for the unit DB blocks ahead as soon as it has consumed a unit.
 //
 // gridDim.y > 1 splits K over workgroups: each writes its fp32 partial sums (after the usual reduction over
 // its own waves) to its slot of `ws`, takes a ticket, and the workgroup that draws the last ticket of an
