@@ -127,6 +127,36 @@ static int check_case(int M, int K, int N, int G, bool with_bias) {
     fails += diff != 0;
   }
 
+  if (M <= 4 && K % 128 == 0 && K >= 256) {
+    // The decode kernel with K split over two workgroups per output slot: on a workspace from hipMalloc (zeroed
+    // once), then on the library's own device array, which needs no allocation at all; same launch, same bits.
+    const size_t ws_bytes = w4a16_decode_workspace_bytes(K, N, 1, W4A16_EPI_NONE, 1, 8, 2);
+    void* d_ws = nullptr;
+    HIP_OK(hipMalloc(&d_ws, ws_bytes));
+    HIP_OK(hipMemsetAsync(d_ws, 0, ws_bytes, stream));
+    std::vector<uint16_t> first((size_t)M * N);
+    for (int round = 0; round < 2; ++round) {
+      HIP_OK(hipMemsetAsync(d_out, 0xff, (size_t)M * N * 2, stream));
+      expect_ok(round == 0 ? w4a16_gemm_packed_f16_decode_cfg(d_x, 0, d_pw, d_ps, with_bias ? d_bias : nullptr, d_out, 0,
+                                                              M, K, N, G, 1, W4A16_EPI_NONE, 1, 8, 0, 2, d_ws, ws_bytes,
+                                                              stream)
+                           : w4a16_gemm_packed_f16_decode_static(d_x, 0, d_pw, d_ps, with_bias ? d_bias : nullptr, d_out,
+                                                                 0, M, K, N, G, 1, W4A16_EPI_NONE, 1, 8, 0, 2, stream),
+                round == 0 ? "w4a16_gemm_packed_f16_decode_cfg" : "w4a16_gemm_packed_f16_decode_static");
+      compare(round == 0 ? "decode, K split, workspace  " : "decode, K split, static     ", with_bias);
+      if (round == 0) first = got;
+    }
+    size_t diff = 0;
+    for (size_t i = 0; i < got.size(); ++i) diff += got[i] != first[i];
+    std::printf("%s decode static vs workspace: %zu elements differ\n", diff ? "FAIL" : "ok  ", diff);
+    fails += diff != 0;
+    if (w4a16_gemm_packed_f16_decode_cfg(d_x, 0, d_pw, d_ps, nullptr, d_out, 0, M, K, N, G, 1, W4A16_EPI_NONE, 1, 8, 0, 2,
+                                         d_ws, ws_bytes - 16, stream) != W4A16_E_WORKSPACE)
+      ++fails;
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipFree(d_ws));
+  }
+
   for (int packed = 0; packed < 2; ++packed) {
     expect_ok(packed ? w4a16_dequantize_packed_f16(d_pw, d_ps, d_deq, K, N, G, stream)
                      : w4a16_dequantize_f16(d_qw, d_sc, d_qz, d_deq, K, N, G, stream),
@@ -156,6 +186,7 @@ int main() {
   }
   int fails = 0;
   fails += check_case(1, 512, 256, 128, false);
+  fails += check_case(3, 1536, 272, 128, true);
   fails += check_case(7, 384, 200, 64, true);
   fails += check_case(40, 640, 416, 32, false);
   fails += check_case(130, 1024, 1376, 128, true);
