@@ -42,8 +42,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <stdlib.h>
-
 #include <mutex>
 
 #include "../../include/w4a16.h"
@@ -2404,12 +2402,6 @@ size_t decode_lds_bytes(int t, int waves, int nb_max, int M, int G) {
   return (size_t)waves * nb_max * 1024 + (size_t)waves * t * 256;
 }
 
-// Developer switch (W4A16_NO_STEAL=1 in the environment): the plain round-robin split of K over the waves.
-bool depth_steal_env() {
-  static const bool on = getenv("W4A16_NO_STEAL") == nullptr;
-  return on;
-}
-
 template <int T, int W, int DB>
 int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
   constexpr bool kPlain = T <= 4;
@@ -2438,7 +2430,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   e.wstride = a.KBS * 1024, e.sstride = a.NG * 64;
   // every wave of every split must own at least two blocks (the shortest split is the last one)
   const int last_split = a.KB - (splits - 1) * kb_per_split;
-  e.steal = (W >= 8 && last_split >= 2 * W && depth_steal_env()) ? 1 : 0;
+  e.steal = (W >= 8 && last_split >= 2 * W) ? 1 : 0;
   e.splits = splits, e.gx = gx;
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
   if (act) {
@@ -2734,8 +2726,8 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kMaxDevices] = {};
 
-// The current device's copy of `scratch` (looked up and cleared on the first call on that device).
-int static_scratch(hipStream_t s, void** out) {
+// The current device's copy of `scratch` (looked up on the first call on that device).
+int static_scratch(void** out) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
@@ -2750,13 +2742,9 @@ int static_scratch(hipStream_t s, void** out) {
       g_last_hip_error = (int)e;
       return W4A16_E_LAUNCH;
     }
-    // the counters must start at zero (the loader zero-fills the array; this covers a process that has
-    // already lost a launch half-way); afterwards the kernels themselves put every counter back
-    e = hipMemsetAsync(ptr, 0, kTicketBytes, s);
-    if (e != hipSuccess) {
-      g_last_hip_error = (int)e;
-      return W4A16_E_LAUNCH;
-    }
+    // The counters must start at zero: the loader zero-fills the array, and every kernel puts the counters it
+    // used back to zero before it ends, so nothing is cleared here (a clear enqueued on this call's stream
+    // could run beside a launch that another stream already has on the array).
     g_scratch_ptr[dev] = ptr;
   }
   *out = g_scratch_ptr[dev];
@@ -3056,7 +3044,7 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
     return W4A16_E_WORKSPACE;
   void* ptr = nullptr;
   if (splits > 1) {
-    const int rc = static_scratch(static_cast<hipStream_t>(stream), &ptr);
+    const int rc = static_scratch(&ptr);
     if (rc) return rc;
   }
   return w4a16_gemm_packed_f16_decode_cfg(x, x_batch_stride, packed_w, packed_sz, bias, out, out_batch_stride, M, K,
