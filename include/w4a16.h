@@ -220,11 +220,11 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
- * The decode kernel (up to 4 rows) with an explicit launch shape, for tuning and tests; batching and epilogues as
- * for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
+ * The decode kernel (up to 16 rows; the K split up to 4) with an explicit launch shape, for tuning and tests;
+ * batching and epilogues as for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
  * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
- * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and stages its activations in a private
- * piece of LDS.  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
+ * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and, up to 4 rows, stages its activations
+ * in a private piece of LDS (5-16 rows: fragments straight from L2).  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
  * `workspace`, and the one that arrives last adds them in split order, so the result does not depend on timing.
  * `workspace` (16-byte aligned; may be NULL when splits == 1) must hold w4a16_decode_workspace_bytes(...) bytes,
  * zero before its first use: the kernels return every counter they touch to zero, so one buffer serves any
@@ -259,7 +259,7 @@ int w4a16_launch_shape_ws(int M, int K, int N, int G, int batch, int epilogue, i
  * no allocator at all - neither hipMalloc / hipFree nor any routine that allocates.  No counterpart in the
  * reference; it is for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
  * that forbid allocation.  t == 0 takes the launch shape the library picks when it has a workspace (waves, depth
- * and splits are then ignored; W4A16_E_SHAPE if the problem is not one for the decode kernel, i.e. more than 4
+ * and splits are then ignored; W4A16_E_SHAPE if the problem is not one for the decode kernel, i.e. more than 16
  * rows or a shape it does not admit).  A launch that needs more than the array holds
  * (w4a16_decode_workspace_bytes(...) > w4a16_static_scratch_bytes()) is refused with W4A16_E_WORKSPACE and
  * nothing is enqueued.  Every GPU holds its own copy of the array until the process ends, and every call on a
@@ -282,7 +282,7 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
  *                LDS_STAGED  (mt, t, nw, kw)        16-row / 16-column tiles
  *                MFMA32      (mt, t, 1, kw)         32-row / 32-column tiles, private slabs per wavefront
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
- *                DECODE      (1, t, waves, splits)  up to 4 rows
+ *                DECODE      (1, t, waves, splits)  up to 16 rows
  */
 enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFMA32 = 2, W4A16_KERNEL_MFMA32_SHARED = 3,
        W4A16_KERNEL_DECODE = 4 };

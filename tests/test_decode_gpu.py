@@ -1,4 +1,4 @@
-"""GPU parity of the decode kernel (up to 4 rows; w4a16_gemm_packed_f16_decode_cfg / _ws of the C ABI) against the
+"""GPU parity of the decode kernel (up to 16 rows; w4a16_gemm_packed_f16_decode_cfg / _ws of the C ABI) against the
 oracle: every built (tiles, waves) shape at both prefetch depths, with and without a split of K over workgroups,
 every group size the kernel admits, bias / fused-activation / add-to-out epilogues, batched and masked launches.
 
@@ -74,7 +74,7 @@ def test_every_decode_shape(L, ops, cuda, G):
     N = 400
     ws = ops.gemm_workspace(cuda, 1 << 20)
     for K in (1280, 2816):
-        for M in (1, 3, 4):
+        for M in (1, 3, 4, 5, 9, 16):
             x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=G + K + M)
             want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
             bias = (np.random.default_rng(M).standard_normal(N) * 0.2).astype(np.float16)
@@ -83,7 +83,7 @@ def test_every_decode_shape(L, ops, cuda, G):
             for t, waves in decode_shapes(L):
                 unsplit = None
                 for depth in (1, 2):
-                    for splits in (1, 2, 3):
+                    for splits in ((1, 2, 3) if M <= 4 else (1, )):  # (the K split is built for up to 4 rows)
                         what = f"G={G} K={K} M={M} t={t} waves={waves} depth={depth} splits={splits}"
                         y = launch(L, cuda, tx, packed, K, N, G, t, waves, depth, splits, ws)
                         assert_parity(y.cpu().numpy(), want, exact, what)
@@ -95,8 +95,9 @@ def test_every_decode_shape(L, ops, cuda, G):
                             ulps = 2.0**-9 * np.abs(want.astype(np.float64)) + 1e-6
                             assert (np.abs(y.float().cpu().numpy() - unsplit.float().cpu().numpy()) <= ulps).all(), what
                 # bias: an fp16 add on the fp16 result, as `out + bias` (awq.py:163-164)
-                yb = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 2, ws, bias=tb)
-                y2 = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 2, ws)
+                sp = 2 if M <= 4 else 1
+                yb = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, sp, ws, bias=tb)
+                y2 = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, sp, ws)
                 assert torch.equal(yb, y2 + tb), (G, K, M, t, waves)
     # every counter went back to zero: nothing but partial sums is left behind the ticket region
     assert int(ws[:65536].view(torch.int32).abs().max().item()) == 0
@@ -139,7 +140,10 @@ def test_workspace_errors_and_sizes(L, ops, cuda):
     launch(L, cuda, tx, packed, K, N, G, 5, 8, 0, 1, None, expect=-5)    # not a built shape
     launch(L, cuda, tx, packed, K, N, G, 1, 8, 3, 1, None, expect=-5)    # depth is 0, 1 or 2
     x5 = dev_t(orc.make_inputs(5, K, N, G, seed=6)[0], cuda)
-    launch(L, cuda, x5, packed, K, N, G, 1, 8, 0, 1, None, expect=-5)    # more than 4 rows
+    launch(L, cuda, x5, packed, K, N, G, 1, 8, 0, 2, ws_ok := torch.zeros(need, dtype=torch.uint8, device=cuda),
+           expect=-5)                                                      # the K split takes up to 4 rows
+    x17 = dev_t(orc.make_inputs(17, K, N, G, seed=6)[0], cuda)
+    launch(L, cuda, x17, packed, K, N, G, 1, 8, 0, 1, None, expect=-5)   # more than 16 rows
     assert L.lib.w4a16_strerror(-9).startswith(b"workspace too small")
     # splits beyond the k-blocks are trimmed, not an error: 8 blocks over "8 splits" of one block each
     ws = ops.gemm_workspace(cuda, L.lib.w4a16_decode_workspace_bytes(K, N, 1, 0, 1, 8, 8))
@@ -147,7 +151,7 @@ def test_workspace_errors_and_sizes(L, ops, cuda):
     assert_parity(y.cpu().numpy(), orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz), "8 splits")
 
 
-@pytest.mark.parametrize("M", [1, 4])
+@pytest.mark.parametrize("M", [1, 4, 7, 16])
 def test_decode_fused_activation_and_add(L, ops, cuda, M):
     K, N, G = 1536, 448, 128  # 14 + 14 gate / up tiles, 12 k-blocks
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=40 + M)
@@ -166,7 +170,7 @@ def test_decode_fused_activation_and_add(L, ops, cuda, M):
             if t % 2:
                 launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None, bias=b_t, epilogue=1, expect=-5)
                 continue
-            for splits in (1, 2, 3):
+            for splits in ((1, 2, 3) if M <= 4 else (1, )):
                 got = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=b_t, epilogue=1)
                 got = got.float().cpu().numpy().astype(np.float64)
                 assert not np.isnan(got).any()
@@ -176,7 +180,7 @@ def test_decode_fused_activation_and_add(L, ops, cuda, M):
     # residual + linear(x) in one launch: bit-identical to the two fp16 steps
     res = (torch.randn(M, N, device=cuda) * 0.5).half()
     for t, waves in decode_shapes(L):
-        for splits in (1, 2):
+        for splits in ((1, 2) if M <= 4 else (1, )):
             plain = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=tb)
             out = res.clone()
             launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=tb, epilogue=2, out=out)
@@ -212,6 +216,18 @@ def test_decode_batched_and_masked(L, ops, cuda):
             assert (out[e].float() - full[e].float()).abs().max().item() <= 2e-3
         else:
             assert (out[e] == 7.0).all()
+
+
+def test_decode_batched_nine_rows(L, ops, cuda):
+    E, M, K, N, G = 3, 9, 1024, 272, 128
+    probs = [orc.make_inputs(M, K, N, G, seed=80 + e) for e in range(E)]
+    packed = ops.awq_repack_batch([dev_t(p[1], cuda) for p in probs], [dev_t(p[2], cuda) for p in probs],
+                                  [dev_t(p[3], cuda) for p in probs])
+    xs = dev_t(np.stack([p[0] for p in probs]), cuda)
+    for t, waves in ((1, 16), (2, 8)):
+        y = launch(L, cuda, xs, packed, K, N, G, t, waves, 0, 1, None, batch=E, x_stride=M * K)
+        for e, (x, qw, s, qz) in enumerate(probs):
+            assert_parity(y[e].cpu().numpy(), orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz), f"problem {e}")
 
 
 def test_library_choice_with_a_workspace(L, ops, cuda):

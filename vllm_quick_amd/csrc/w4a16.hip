@@ -15,9 +15,10 @@
 // The GEMM kernels share that layout and the bit-exact register conversion
 // (fp16((q - z) * s), as the reference computes it):
 //
-//  * gemm_decode_kernel (up to 4 rows): weights in 1-KiB units paced one or two
-//    128-k blocks ahead per wave, activations staged once per wave in private LDS,
-//    optionally K split over workgroups through a workspace (see its comment).
+//  * gemm_decode_kernel (up to 16 rows): weights in 1-KiB units paced one or two
+//    128-k blocks ahead per wave; up to 4 rows the activations are staged once per
+//    wave in private LDS and K can be split over workgroups through a workspace
+//    (see its comment).
 //  * gemm_packed_kernel ("streaming", up to 32 rows): a workgroup owns T column
 //    tiles x MT row tiles of the output over the WHOLE of K; its W wavefronts
 //    split K between them (wave w takes 128-k blocks w, w+W, ...), stream their
@@ -587,7 +588,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ---------------------------------------------------------------------------
-// Decode GEMM on the private layout: up to 4 rows, paced weight stream, optional K split over workgroups
+// Decode GEMM on the private layout: up to 16 rows, paced weight stream, optional K split over workgroups
 // ---------------------------------------------------------------------------
 // The streaming kernel above requests everything a wave will ever need at once, activations included, in
 // fragment-shaped loads: at one row a wave of the 4096 x 11008 launch issues 20 vector-memory instructions for
@@ -620,7 +621,10 @@ struct DecodeArgs {
   int gx;             // workgroup columns (gridDim.x)
 };
 
-template <int T, int W, int DB, int SZS, bool ACT = false>
+// XLDS = false serves 5-16 rows: the activations then come as B fragments straight from L2, one block ahead of
+// the block being worked on (at 16 rows a fragment load has no lane to spare, and 16 rows x 256 bytes per block
+// and wave would not fit LDS), the waves park whole 16 x 16 partial tiles, and waves 0..H-1 each sum one tile.
+template <int T, int W, int DB, int SZS, bool ACT = false, bool XLDS = true>
 __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
   fetch_args_now(ga);
@@ -727,17 +731,35 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[j], acc[t], 0, 0, 0);
     }
   };
-  // One block from the registers `u`; with REFILL each unit's registers are asked to fetch the same tile's unit
-  // of block kb_refill as soon as the unit is consumed.  (A compile-time flag: a load under a run-time branch
-  // makes the compiler wait for every load in flight.)
-  auto step = [&](auto refill_, int bi, Unit (&u)[T], int kb_refill) {
-    constexpr bool REFILL = decltype(refill_)::value != 0;
-    f16x8 xf[4];
+  // Without LDS staging: the B fragments of a block (row min(n16, M - 1), k = 32 j + 8 kq .. + 7), 4 loads
+  const uint32_t xfrag_lane = ((uint32_t)min(n16, a.M - 1) * a.K + kq * 8) * 2u;
+  auto load_x = [&](int kb, f16x8 (&xf)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[j] + bi * 1024);
+    for (int j = 0; j < 4; ++j)
+      xf[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, xfrag_lane, (kb * 128 + j * 32) * 2, 0));
+  };
+  // One block from the registers `u`; with REFILL each unit's registers are asked to fetch the same tile's unit
+  // of block kb_refill as soon as the unit is consumed; with XNEXT (fragments from L2 only) the next block's
+  // fragments are requested into `xnext` first.  (Compile-time flags: a load under a run-time branch makes the
+  // compiler wait for every load in flight.)
+  auto step = [&](auto refill_, auto xnext_, int bi, Unit (&u)[T], f16x8 (&xcur)[4], f16x8 (&xnext)[4], int kb_refill,
+                  int kb_xnext) {
+    constexpr bool REFILL = decltype(refill_)::value != 0;
+    constexpr bool XNEXT = decltype(xnext_)::value != 0;
+    f16x8 xl[4];
+    if constexpr (XLDS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[j] + bi * 1024);
+    } else if constexpr (XNEXT) {
+      load_x(kb_xnext, xnext);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      compute_unit(t, u[t], xf);
+      if constexpr (XLDS)
+        compute_unit(t, u[t], xl);
+      else
+        compute_unit(t, u[t], xcur);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (REFILL) {
         load_unit(t, kb_refill, u[t]);
@@ -750,10 +772,15 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   };
 
   if (nblk > 0) {
-    // activations first: they come from L2 and are back before the weights
-    for (int bi = 0; bi < nblk; ++bi)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + bi * 1024), 16, xlane,
-                                               kb_of(bi) * 256, 0, 0);
+    f16x8 xa[4], xb[4];
+    if constexpr (XLDS) {
+      // activations first: they come from L2 and are back before the weights
+      for (int bi = 0; bi < nblk; ++bi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + bi * 1024), 16, xlane,
+                                                 kb_of(bi) * 256, 0, 0);
+    } else {
+      load_x(kb0, xa);
+    }
     __builtin_amdgcn_sched_barrier(0);
     Unit u0[T], u1[T];
 #pragma unroll
@@ -767,26 +794,39 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
     // everything but the DB * T units just requested has landed: the activations are in LDS
-    wait_vmcnt<DB * T * UL>();
+    if constexpr (XLDS) wait_vmcnt<DB * T * UL>();
+    constexpr Flag<1> Y{};
+    constexpr Flag<0> N{};
+    // Even blocks read fragment set xa, odd blocks xb (LDS staging ignores both).
     if constexpr (DB == 1) {
       int bi = 0;
-      for (; bi + 1 < nblk; ++bi) step(Flag<1>{}, bi, u0, kb_of(bi + 1));
-      step(Flag<0>{}, bi, u0, 0);
+      for (; bi + 2 < nblk; bi += 2) {
+        step(Y, Y, bi, u0, xa, xb, kb_of(bi + 1), kb_of(bi + 1));
+        step(Y, Y, bi + 1, u0, xb, xa, kb_of(bi + 2), kb_of(bi + 2));
+      }
+      if (nblk - bi == 2) {
+        step(Y, Y, bi, u0, xa, xb, kb_of(bi + 1), kb_of(bi + 1));
+        step(N, N, bi + 1, u0, xb, xa, 0, 0);
+      } else {
+        step(N, N, bi, u0, xa, xb, 0, 0);
+      }
     } else {
       // u0 holds block bi, u1 block bi + 1; blocks that have a block two ahead go two per trip
       int bi = 0;
       for (; bi + 4 <= nblk; bi += 2) {
-        step(Flag<1>{}, bi, u0, kb_of(bi + 2));
-        step(Flag<1>{}, bi + 1, u1, kb_of(bi + 3));
+        step(Y, Y, bi, u0, xa, xb, kb_of(bi + 2), kb_of(bi + 1));
+        step(Y, Y, bi + 1, u1, xb, xa, kb_of(bi + 3), kb_of(bi + 2));
       }
       const int rest = nblk - bi;
       if (rest == 3) {
-        step(Flag<1>{}, bi, u0, kb_of(bi + 2));
-        step(Flag<0>{}, bi + 1, u1, 0);
-        step(Flag<0>{}, bi + 2, u0, 0);
+        step(Y, Y, bi, u0, xa, xb, kb_of(bi + 2), kb_of(bi + 1));
+        step(N, Y, bi + 1, u1, xb, xa, 0, kb_of(bi + 2));
+        step(N, N, bi + 2, u0, xa, xb, 0, 0);
+      } else if (rest == 2) {
+        step(N, Y, bi, u0, xa, xb, 0, kb_of(bi + 1));
+        step(N, N, bi + 1, u1, xb, xa, 0, 0);
       } else {
-        step(Flag<0>{}, bi, u0, 0);
-        if (rest == 2) step(Flag<0>{}, bi + 1, u1, 0);
+        step(N, N, bi, u0, xa, xb, 0, 0);
       }
     }
   }
@@ -795,6 +835,44 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   // Reduction over the waves: of a 16 x 16 partial tile only the lanes of tokens 0..3 (lane & 15 < 4) hold
   // anything that is stored; they park their 16 bytes as [wave][tile][token][lane >> 4] and the first wave
   // sums the W partials of every (tile, token, 4-column group), one lane each.
+  if constexpr (!XLDS) {
+    // 5-16 rows: whole partial tiles (1 KiB per wave and tile), wave ti sums tile ti (and its up-half twin)
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[(w * T + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    STAMP(11);
+    if (w >= H) return;
+    const int ti = w;
+    f32x4 v = red[ti * 64 + lane], vu = v;
+#pragma unroll
+    for (int s = 1; s < W; ++s) v += red[(s * T + ti) * 64 + lane];
+    if constexpr (ACT) {
+      vu = red[(ti + H) * 64 + lane];
+#pragma unroll
+      for (int s = 1; s < W; ++s) vu += red[(s * T + ti + H) * 64 + lane];
+    }
+    auto finish = [&](f32x4 r, int n_bias) {
+      f16x4 h = f16x4{(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w};
+      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+      return h;
+    };
+    const int nt = nt0 + ti, n = nt * 16 + kq * 4, tok = n16;
+    if (tok >= a.M) return;
+    if constexpr (ACT) {
+      const int NH = a.N / 2;
+      if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+    } else {
+      if (nt < a.NT && n < a.N) {
+        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)tok * a.N + n);
+        f16x4 hv = finish(v, n);
+        if (a.add_out) hv = *dst + hv;
+        *dst = hv;
+      }
+    }
+    STAMP(12);
+    return;
+  }
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + W * nb_max * 1024);
   f32x4* const ws = e.ws;
   unsigned* const tickets = e.tickets;
@@ -2368,13 +2446,14 @@ int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, 
 }
 
 // ---- decode kernel (up to 4 rows) ----
-constexpr int kDecodeMaxRows = 4;
+constexpr int kDecodeMaxRows = 4;    // with LDS staging, the compact reduction and the optional K split
+constexpr int kDecodeMaxRowsL2 = 16;  // with fragments straight from L2 (no K split)
 constexpr int kMaxSplits = 8;
 
 // What the decode kernel's addressing admits: whole 128-k blocks, 32-bit byte offsets, and a group size whose
 // group index is a shift or one multiply away from the block index.
 bool decode_ok(const GemmArgs& a) {
-  if (a.M > kDecodeMaxRows || a.K % 128) return false;
+  if (a.M > kDecodeMaxRowsL2 || a.K % 128 || (long long)a.M * a.K * 2 >= (1LL << 31)) return false;
   if (!(a.G == 32 || a.G == 64 || (a.G % 128 == 0 && a.G / 128 <= 64))) return false;
   if (a.KB >= 1024) return false;
   if ((long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.NT * a.NG * 64 >= (1LL << 31)) return false;
@@ -2398,7 +2477,8 @@ size_t decode_ws_bytes(int batch, int gx, int splits, bool act) {
 // block, then the reduction's partial sums
 int decode_nsz(int G) { return G % 128 == 0 ? 1 : G == 64 ? 2 : 4; }
 size_t decode_lds_bytes(int t, int waves, int nb_max, int M, int G) {
-  (void)M, (void)G;
+  (void)G;
+  if (M > kDecodeMaxRows) return (size_t)waves * t * 1024;  // whole partial tiles, no staged activations
   return (size_t)waves * nb_max * 1024 + (size_t)waves * t * 256;
 }
 
@@ -2408,6 +2488,8 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   constexpr bool kAct = T % 2 == 0 && T / 2 <= 4;
   if (!decode_ok(a) || (act && a.N % 32)) return W4A16_E_SHAPE;
   if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
+  const bool xlds = a.M <= kDecodeMaxRows;
+  if (!xlds && splits > 1) return W4A16_E_SHAPE;  // the K split is built for up to 4 rows
   const int kb_per_split = ceil_div(a.KB, splits);
   splits = ceil_div(a.KB, kb_per_split);  // no empty split
   const int nb_max = ceil_div(kb_per_split, W);
@@ -2433,25 +2515,19 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   e.steal = (W >= 8 && last_split >= 2 * W) ? 1 : 0;
   e.splits = splits, e.gx = gx;
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
-  if (act) {
-    if constexpr (kAct) {
-      if (a.G % 128 == 0)
-        kern = gemm_decode_kernel<T, W, DB, 4, true>;
-      else if (a.G == 64)
-        kern = gemm_decode_kernel<T, W, DB, 2, true>;
-      else
-        kern = gemm_decode_kernel<T, W, DB, 1, true>;
-    }
-  } else {
-    if constexpr (kPlain) {
-      if (a.G % 128 == 0)
-        kern = gemm_decode_kernel<T, W, DB, 4>;
-      else if (a.G == 64)
-        kern = gemm_decode_kernel<T, W, DB, 2>;
-      else
-        kern = gemm_decode_kernel<T, W, DB, 1>;
-    }
+  const int szs = a.G % 128 == 0 ? 4 : a.G == 64 ? 2 : 1;
+#define W4A16_PICK(SZS_)                                                                         \
+  if (szs == SZS_) {                                                                             \
+    if (act) {                                                                                   \
+      if constexpr (kAct) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, true, true>           \
+                                      : gemm_decode_kernel<T, W, DB, SZS_, true, false>;         \
+    } else {                                                                                     \
+      if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, true>        \
+                                        : gemm_decode_kernel<T, W, DB, SZS_, false, false>;      \
+    }                                                                                            \
   }
+  W4A16_PICK(4) W4A16_PICK(2) W4A16_PICK(1)
+#undef W4A16_PICK
   if (!kern) return W4A16_E_SHAPE;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2672,12 +2748,12 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false) {
   return best;
 }
 
-// The decode kernel takes over the streaming kernel's launches of up to 4 rows wherever it is built for the
-// shape chosen.  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
+// The decode kernel takes over the streaming kernel's launches of up to 16 rows wherever it is built for the
+// shape chosen (4-7 % faster at 5-16 rows, 8-20 % at up to 4).  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
 // over K as well.
 Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool have_ws) {
   Choice c = choose_cfg(M, K, N, batch, act);
-  if (c.tiled || c.mt != 1 || M > kDecodeMaxRows || !W4A16_DECODE) return c;
+  if (c.tiled || c.mt != 1 || M > kDecodeMaxRowsL2 || !W4A16_DECODE) return c;
   GemmArgs probe;
   probe.M = M, probe.K = K, probe.N = N, probe.G = G;
   probe.NT = ceil_div(N, 16), probe.KB = ceil_div(K, 128), probe.KBS = padded_kblocks(K), probe.NG = K / G;
@@ -2694,7 +2770,7 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   const int nb_max = ceil_div(probe.KB, c.a);
   if (decode_lds_bytes(c.t, c.a, nb_max + 1, M, G) > 160 * 1024) return c;
   c.splits = 1;
-  if (have_ws) {
+  if (have_ws && M <= kDecodeMaxRows) {
     // A split pays where a wave's chain of blocks is long (its requests go out a block or two at a time, a
     // memory latency each) and the workgroups are few: from K = 12800 on, about 40 blocks per split
     // (14336 x 512 at 1 row 7.4 -> 6.0 us with 3 splits, 16384 x 1024 8.1 -> 6.7; at K = 11008 it is a wash and
