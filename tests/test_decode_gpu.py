@@ -34,8 +34,9 @@ def ops():
     return ops
 
 
-def decode_shapes(L):
-    return [(t, w) for t, w, _ in L.built_shapes(4)]
+def decode_shapes(L, act=False):
+    """(tiles, waves) of the decode kernel; the plain GEMM takes up to 4 tiles, the fused activation the even counts."""
+    return [(t, w) for t, w, _ in L.built_shapes(4) if (t % 2 == 0 if act else t <= 4)]
 
 
 def assert_parity(got, want, exact, what):
@@ -63,9 +64,9 @@ def launch(L, cuda, x, packed, K, N, G, t, waves, depth=0, splits=1, ws=None, bi
 
 
 def test_decode_shapes_are_enumerated(L):
-    shapes = decode_shapes(L)
-    assert len(shapes) == 7  # a shape added to the library is a shape tested here
-    assert (3, 16) in shapes and (4, 8) in shapes
+    shapes = decode_shapes(L) + [c for c in decode_shapes(L, act=True) if c[0] > 4]
+    assert len(shapes) == 11 == len(L.built_shapes(4))  # a shape added to the library is a shape tested here
+    assert (3, 16) in shapes and (4, 8) in shapes and (8, 8) in shapes and (2, 4) in shapes
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
@@ -169,7 +170,8 @@ def test_decode_fused_activation_and_add(L, ops, cuda, M):
         for t, waves in decode_shapes(L):
             if t % 2:
                 launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None, bias=b_t, epilogue=1, expect=-5)
-                continue
+        launch(L, cuda, tx, packed, K, N, G, 6, 8, 0, 1, None, bias=b_t, expect=-5)  # 6 tiles: fused activation only
+        for t, waves in decode_shapes(L, act=True):
             for splits in ((1, 2, 3) if M <= 4 else (1, )):
                 got = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=b_t, epilogue=1)
                 got = got.float().cpu().numpy().astype(np.float64)

@@ -794,7 +794,8 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
     // everything but the DB * T units just requested has landed: the activations are in LDS
-    if constexpr (XLDS) wait_vmcnt<DB * T * UL>();
+    // (the counter has 6 bits: with more than 63 loads behind the DMA a few of the weights are waited for too)
+    if constexpr (XLDS) wait_vmcnt<(DB * T * UL < 63 ? DB * T * UL : 63)>();
     constexpr Flag<1> Y{};
     constexpr Flag<0> N{};
     // Even blocks read fragment set xa, odd blocks xb (LDS staging ignores both).
@@ -2541,8 +2542,9 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   return launched();
 }
 
-// (t, waves) of the decode kernel; the fused activation takes the even t
-#define W4A16_FOR_EACH_DECODE(X) X(1, 16) X(2, 16) X(3, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8)
+// (t, waves) of the decode kernel; the fused activation takes the even t, the plain GEMM t <= 4
+#define W4A16_FOR_EACH_DECODE(X) \
+  X(1, 16) X(2, 16) X(3, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(6, 8) X(8, 8) X(2, 4) X(4, 4)
 
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
@@ -2562,7 +2564,7 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
 }
 
 bool decode_built(int t, int waves, bool act) {
-  if (act && t % 2) return false;
+  if (act ? t % 2 != 0 : t > 4) return false;  // (6 and 8 tiles: 3 + 3 / 4 + 4 gate and up tiles only)
 #define X(T_, W_) \
   if (t == T_ && waves == W_) return true;
   W4A16_FOR_EACH_DECODE(X)
