@@ -220,7 +220,8 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
- * The decode kernel (up to 16 rows; the K split up to 4) with an explicit launch shape, for tuning and tests;
+ * The decode kernel (up to 16 rows; the K split up to 4 rows and 4 tiles or tile pairs per workgroup) with an
+ * explicit launch shape, for tuning and tests;
  * batching and epilogues as for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
  * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
  * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and, up to 4 rows, stages its activations

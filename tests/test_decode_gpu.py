@@ -35,8 +35,13 @@ def ops():
 
 
 def decode_shapes(L, act=False):
-    """(tiles, waves) of the decode kernel; the plain GEMM takes up to 4 tiles, the fused activation the even counts."""
-    return [(t, w) for t, w, _ in L.built_shapes(4) if (t % 2 == 0 if act else t <= 4)]
+    """(tiles, waves) of the decode kernel; the fused activation takes the even tile counts (gate / up pairs)."""
+    return [(t, w) for t, w, _ in L.built_shapes(4) if (t % 2 == 0 or not act)]
+
+
+def splittable(t, act=False):
+    """The K split is built for workgroups of up to 4 tiles (or gate / up tile pairs)."""
+    return (t // 2 if act else t) <= 4
 
 
 def assert_parity(got, want, exact, what):
@@ -64,9 +69,10 @@ def launch(L, cuda, x, packed, K, N, G, t, waves, depth=0, splits=1, ws=None, bi
 
 
 def test_decode_shapes_are_enumerated(L):
-    shapes = decode_shapes(L) + [c for c in decode_shapes(L, act=True) if c[0] > 4]
-    assert len(shapes) == 11 == len(L.built_shapes(4))  # a shape added to the library is a shape tested here
-    assert (3, 16) in shapes and (4, 8) in shapes and (8, 8) in shapes and (2, 4) in shapes
+    shapes = decode_shapes(L)
+    assert len(shapes) == 12 == len(L.built_shapes(4))  # a shape added to the library is a shape tested here
+    assert (3, 16) in shapes and (6, 16) in shapes and (4, 8) in shapes and (8, 8) in shapes and (2, 4) in shapes
+    assert set(decode_shapes(L, act=True)) < set(shapes)
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
@@ -84,7 +90,7 @@ def test_every_decode_shape(L, ops, cuda, G):
             for t, waves in decode_shapes(L):
                 unsplit = None
                 for depth in (1, 2):
-                    for splits in ((1, 2, 3) if M <= 4 else (1, )):  # (the K split is built for up to 4 rows)
+                    for splits in ((1, 2, 3) if M <= 4 and splittable(t) else (1, )):  # (up to 4 rows and 4 tiles)
                         what = f"G={G} K={K} M={M} t={t} waves={waves} depth={depth} splits={splits}"
                         y = launch(L, cuda, tx, packed, K, N, G, t, waves, depth, splits, ws)
                         assert_parity(y.cpu().numpy(), want, exact, what)
@@ -96,7 +102,7 @@ def test_every_decode_shape(L, ops, cuda, G):
                             ulps = 2.0**-9 * np.abs(want.astype(np.float64)) + 1e-6
                             assert (np.abs(y.float().cpu().numpy() - unsplit.float().cpu().numpy()) <= ulps).all(), what
                 # bias: an fp16 add on the fp16 result, as `out + bias` (awq.py:163-164)
-                sp = 2 if M <= 4 else 1
+                sp = 2 if M <= 4 and splittable(t) else 1
                 yb = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, sp, ws, bias=tb)
                 y2 = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, sp, ws)
                 assert torch.equal(yb, y2 + tb), (G, K, M, t, waves)
@@ -139,6 +145,7 @@ def test_workspace_errors_and_sizes(L, ops, cuda):
     launch(L, cuda, tx, packed, K, N, G, 1, 8, 0, 2, None, expect=-4)    # a split needs a workspace
     launch(L, cuda, tx, packed, K, N, G, 1, 8, 0, 9, small, expect=-5)   # at most 8 splits
     launch(L, cuda, tx, packed, K, N, G, 5, 8, 0, 1, None, expect=-5)    # not a built shape
+    launch(L, cuda, tx, packed, K, N, G, 6, 8, 0, 2, small, expect=-5)   # the K split takes up to 4 tiles a workgroup
     launch(L, cuda, tx, packed, K, N, G, 1, 8, 3, 1, None, expect=-5)    # depth is 0, 1 or 2
     x5 = dev_t(orc.make_inputs(5, K, N, G, seed=6)[0], cuda)
     launch(L, cuda, x5, packed, K, N, G, 1, 8, 0, 2, ws_ok := torch.zeros(need, dtype=torch.uint8, device=cuda),
@@ -170,9 +177,8 @@ def test_decode_fused_activation_and_add(L, ops, cuda, M):
         for t, waves in decode_shapes(L):
             if t % 2:
                 launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None, bias=b_t, epilogue=1, expect=-5)
-        launch(L, cuda, tx, packed, K, N, G, 6, 8, 0, 1, None, bias=b_t, expect=-5)  # 6 tiles: fused activation only
         for t, waves in decode_shapes(L, act=True):
-            for splits in ((1, 2, 3) if M <= 4 else (1, )):
+            for splits in ((1, 2, 3) if M <= 4 and splittable(t, act=True) else (1, )):
                 got = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=b_t, epilogue=1)
                 got = got.float().cpu().numpy().astype(np.float64)
                 assert not np.isnan(got).any()
@@ -182,7 +188,7 @@ def test_decode_fused_activation_and_add(L, ops, cuda, M):
     # residual + linear(x) in one launch: bit-identical to the two fp16 steps
     res = (torch.randn(M, N, device=cuda) * 0.5).half()
     for t, waves in decode_shapes(L):
-        for splits in ((1, 2) if M <= 4 else (1, )):
+        for splits in ((1, 2) if M <= 4 and splittable(t) else (1, )):
             plain = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=tb)
             out = res.clone()
             launch(L, cuda, tx, packed, K, N, G, t, waves, 0, splits, ws, bias=tb, epilogue=2, out=out)

@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   constexpr int H = ACT ? T / 2 : T;       // tiles per half
   static_assert(DB == 1 || DB == 2, "one or two blocks in flight");
   static_assert(!ACT || T % 2 == 0, "gate and up tiles come in pairs");
-  static_assert(H <= 4, "one wave finishes all tiles: 16 lanes per tile or tile pair");
+  static_assert(H <= 8, "one wave finishes all tiles: 16 lanes per tile or tile pair, in one or two passes");
   const int NTH = ACT ? a.NT / 2 : a.NT;   // column tiles per half
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -884,7 +884,10 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   __syncthreads();
   STAMP(11);
   if (w != 0) return;
-  const int ti = lane / 16, tok = (lane >> 2) & 3, grp = lane & 3;
+  constexpr int PASSES = (H * 16 + 63) / 64;  // 16 lanes per tile (pair): one pass up to 4, two up to 8
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+  const int ti = pass * 4 + lane / 16, tok = (lane >> 2) & 3, grp = lane & 3;
   const bool live = ti < H && tok < a.M;
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, vu = v;
   if (live) {
@@ -898,7 +901,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     }
   }
   const int S = e.splits;
-  if (S > 1) {
+  if (PASSES == 1 && S > 1) {  // (the host splits K only for launch shapes of up to 4 tiles or tile pairs)
     constexpr int SLOT = ACT ? 128 : 64;  // f32x4 per workgroup
     const size_t slot = (size_t)blockIdx.z * e.gx + blockIdx.x;
     // Partial sums and tickets travel as device-scope atomic accesses (each one coherent across the XCDs'
@@ -931,7 +934,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     }
     if (lane == 0) __hip_atomic_store(&tickets[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // as the next launch expects it
   }
-  if (!live) return;
+  if (!live) continue;
   auto finish = [&](f32x4 r, int n_bias) {
     f16x4 h = f16x4{(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w};
     if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
@@ -949,6 +952,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       *dst = hv;
     }
   }
+  }  // pass
   STAMP(12);
 #endif
 }
@@ -2485,12 +2489,13 @@ size_t decode_lds_bytes(int t, int waves, int nb_max, int M, int G) {
 
 template <int T, int W, int DB>
 int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
-  constexpr bool kPlain = T <= 4;
-  constexpr bool kAct = T % 2 == 0 && T / 2 <= 4;
+  constexpr bool kPlain = T <= 8;
+  constexpr bool kAct = T % 2 == 0 && T / 2 <= 8;
   if (!decode_ok(a) || (act && a.N % 32)) return W4A16_E_SHAPE;
   if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
   const bool xlds = a.M <= kDecodeMaxRows;
   if (!xlds && splits > 1) return W4A16_E_SHAPE;  // the K split is built for up to 4 rows
+  if (splits > 1 && (act ? T / 2 : T) > 4) return W4A16_E_SHAPE;  // and up to 4 tiles or tile pairs
   const int kb_per_split = ceil_div(a.KB, splits);
   splits = ceil_div(a.KB, kb_per_split);  // no empty split
   const int nb_max = ceil_div(kb_per_split, W);
@@ -2542,18 +2547,28 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   return launched();
 }
 
-// (t, waves) of the decode kernel; the fused activation takes the even t, the plain GEMM t <= 4
+// (t, waves) of the decode kernel; the fused activation takes the even t
 #define W4A16_FOR_EACH_DECODE(X) \
-  X(1, 16) X(2, 16) X(3, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(6, 8) X(8, 8) X(2, 4) X(4, 4)
+  X(1, 16) X(2, 16) X(3, 16) X(6, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(6, 8) X(8, 8) X(2, 4) X(4, 4)
 
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
                     size_t ws_bytes, int depth = 0) {
-  // Two blocks in flight per wave wherever that keeps a workgroup within ~64 KiB of outstanding weights (a CU
-  // takes no more than that in at a time: beyond it the youngest waves' first requests wait for the oldest waves'
-  // second blocks): 8192 x 1280 at 1 row 5.2 us against 5.8 with one block, 11008 x 4096 7.0 against 7.9,
-  // 8192 x 3584 5.6 against 6.9; the 3-tile 16-wave shape (4096 x 11008) stays at one block, 7.0 against 7.4.
-  if (depth == 0) depth = t * waves <= 32 ? 2 : 1;
+  // Two blocks per wave in flight where one would leave the CU short of outstanding requests (8192 x 1280 at
+  // 1 row 5.2 us against 5.8 with one block, 11008 x 4096 7.0 against 7.9, 8192 x 3584 5.6 against 6.9), but no
+  // more than a CU takes in at a time, ~64 KiB (beyond it the youngest waves' first requests wait for the oldest
+  // waves' second blocks; 4096 x 11008 with 3 x 16: 7.0 against 7.4).  That is: up to 16 tile streams per
+  // workgroup always, up to 24 from K = 6144 on (3 tiles x 8 waves: 4096 x 11008 7.2 us with one
+  // block against 7.45 with two, 8192 x 10240 11.0 against 10.4); with 32 streams and more, one block each is
+  // already past what a CU keeps in flight (8192 x 8192 with 2 x 16: 8.85 against 9.16; 4096 x 14336 with
+  // 4 x 8: 8.5 against 9.5).
+  // 2 tiles x 16 waves stay at two blocks from 5 rows on (fragments from L2: 8192 x 8192 at 8 rows 9.6 against
+  // 10.1) and from K = 12800 on (13824 x 5120: 10.6 against 10.9).
+  if (depth == 0) {
+    const int streams = t * waves;
+    depth = (streams < 24 || (streams < 32 && a.K >= 6144) ||
+             (streams == 32 && waves == 16 && (a.M > kDecodeMaxRows || a.K >= 12800))) ? 2 : 1;
+  }
 #define X(T_, W_)                                                                                     \
   if (t == T_ && waves == W_)                                                                         \
     return depth == 1 ? launch_decode<T_, W_, 1>(a, s, batch, act, splits, ws, ws_bytes)              \
@@ -2564,7 +2579,7 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
 }
 
 bool decode_built(int t, int waves, bool act) {
-  if (act ? t % 2 != 0 : t > 4) return false;  // (6 and 8 tiles: 3 + 3 / 4 + 4 gate and up tiles only)
+  if (act && t % 2 != 0) return false;
 #define X(T_, W_) \
   if (t == T_ && waves == W_) return true;
   W4A16_FOR_EACH_DECODE(X)
@@ -2766,6 +2781,18 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
   if (!act && c.a == 8 && M <= 2 && probe.KB >= 100 && col_tiles <= 3 * 256) {
     const int t16 = (int)(col_tiles <= 256 ? 1 : col_tiles <= 512 ? 2 : 3);
     if (decode_lds_bytes(t16, 16, ceil_div(probe.KB, 16) + 1, M, G) <= 160 * 1024) c.t = t16, c.a = 16;
+  }
+  // Three to six tiles per CU: the streaming kernel's order of preference (small workgroups
+  // first) turns round, one workgroup per CU with the fewest tiles on the busiest CU is ahead (5120 x 13824:
+  // 9.35 us with 4 tiles against 10.1 with 2 and 10.4 with 3; 4096 x 14336: 8.5 against 9.3; 4096 x 22016:
+  // 12.0 with 6 against 12.1 with 3).
+  if (!act && c.a == 8 && col_tiles > 3 * 256 && col_tiles < 6 * 256) {
+    static const int order[4] = {6, 4, 3, 2};
+    long long best = -1;
+    for (int i = 0; i < 4; ++i) {
+      const long long load = ceil_div(ceil_div(col_tiles, order[i]), 256) * order[i];
+      if (best < 0 || load < best) best = load, c.t = order[i];
+    }
   }
   if (!decode_built(c.t, c.a, act)) return c;
   const int per_wg = act ? c.t / 2 : c.t;
