@@ -2549,7 +2549,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 
 // (t, waves) of the decode kernel; the fused activation takes the even t
 #define W4A16_FOR_EACH_DECODE(X) \
-  X(1, 16) X(2, 16) X(3, 16) X(6, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(6, 8) X(8, 8) X(2, 4) X(4, 4)
+  X(1, 16) X(2, 16) X(3, 16) X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(6, 8) X(8, 8) X(2, 4) X(4, 4)
 
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
