@@ -313,6 +313,27 @@ int w4a16_stream_read(const void* src, size_t bytes, void* sink, void* stream);
 int w4a16_dequantize_packed_f16(const void* packed_w, const void* packed_sz, void* out, int K,
                                 int N, int G, void* stream);
 
+/*
+ * Expert routing of a Mixtral-style block in one launch (vllm/model_executor/models/mixtral_quant.py:137-150:
+ * softmax over all experts in fp32, top-k, renormalise by the sum of the selected, scatter): router_logits
+ * [tokens, n_experts] fp16 -> weights [tokens, n_local] fp32 for this rank's experts
+ * [first_local, first_local + n_local) (0 where a token did not select the expert; ties go to the lower index)
+ * and, if `mask` is not NULL, mask[e] = 1 if any token selected local expert e, else 0 (int32 [n_local]: the
+ * problem mask of w4a16_gemm_packed_f16_masked).  n_experts <= 64.
+ */
+int w4a16_moe_route_f16(const void* router_logits, void* weights, void* mask, int tokens, int n_experts,
+                        int top_k, int first_local, int n_local, void* stream);
+
+/*
+ * The weighted sum over experts that ends the block (mixtral_quant.py:152-157: `current_hidden_states.mul_(
+ * expert_weights)`, then the sum): out[t, h] = fp16(sum_e float(fp16(float(y[e, t, h]) * weights[t, e]))), e in
+ * expert order, y [n_local, tokens, hidden] fp16 (the batched launch's output), weights as w4a16_moe_route_f16
+ * writes them.  Experts whose weight for a token is 0 are not read: a masked launch's untouched outputs never
+ * reach the sum.  hidden % 8 == 0; y and out 16-byte aligned.
+ */
+int w4a16_moe_combine_f16(const void* y, const void* weights, void* out, int n_local, int tokens, int hidden,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

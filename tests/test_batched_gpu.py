@@ -224,3 +224,91 @@ def test_mixtral_block_skips_unselected_experts_on_gpu(cuda):
                 moe.sparse_max_tokens = 0
                 assert torch.equal(yg, moe(fresh))
                 moe.sparse_max_tokens = 4
+
+
+def framework_route(logits, top_k, first, n):
+    """mixtral_quant.py:137-150 with framework operators (what `MixtralMoE.routing` runs)."""
+    p = torch.nn.functional.softmax(logits, dim=1, dtype=torch.float)
+    p, sel = torch.topk(p, top_k, dim=-1)
+    p /= p.sum(dim=-1, keepdim=True)
+    dense = torch.zeros(logits.shape, dtype=torch.float, device=logits.device).scatter_(1, sel, p)
+    return dense[:, first:first + n]
+
+
+@pytest.mark.parametrize("tokens", [1, 3, 16, 300, 1000])
+def test_moe_route_against_framework_operators(ops, cuda, tokens):
+    """w4a16_moe_route_f16: the routing weights of the reference's block in one launch.  Same selection as
+    softmax / topk / renormalise / scatter, weights to the last bits of fp32 (the kernel's exp and summation
+    order are its own), the problem mask = 'some token selected this expert'."""
+    gen = torch.Generator(device=cuda).manual_seed(tokens)
+    for E, top_k, first, n in ((8, 2, 0, 8), (8, 2, 4, 4), (8, 2, 6, 2), (16, 4, 0, 16), (64, 2, 32, 8), (3, 3, 0, 3)):
+        logits = (torch.randn((tokens, E), generator=gen, device=cuda) * 2).half()
+        want = framework_route(logits, top_k, first, n)
+        w, mask = ops.moe_route(logits, top_k, first, n, want_mask=True)
+        assert w.shape == want.shape and w.dtype == torch.float32 and mask.dtype == torch.int32
+        assert torch.equal(w != 0, want != 0), (E, top_k, first, n)   # (random fp16 logits: ties are rare; see below)
+        assert torch.allclose(w, want, rtol=2e-6, atol=1e-9)
+        assert torch.equal(mask.bool(), (want != 0).any(0))
+        w2, none = ops.moe_route(logits, top_k, first, n)
+        assert none is None and torch.equal(w2, w)
+    # ties go to the lower index, and a row's weights sum to one
+    flat = torch.zeros((2, 8), dtype=torch.float16, device=cuda)
+    w, _ = ops.moe_route(flat, 2)
+    assert torch.equal(w, torch.tensor([[0.5, 0.5, 0, 0, 0, 0, 0, 0]] * 2, device=cuda))
+    with pytest.raises(ValueError):
+        ops.moe_route(flat, 9)             # more selections than experts
+    with pytest.raises(ValueError):
+        ops.moe_route(flat, 2, 4, 8)       # local range past the last expert
+    with pytest.raises(RuntimeError):
+        ops.moe_route(flat.float(), 2)     # fp16 logits only (the gate is an fp16 linear layer)
+
+
+@pytest.mark.parametrize("tokens", [1, 4, 33])
+def test_moe_combine_against_framework_operators(ops, cuda, tokens):
+    """w4a16_moe_combine_f16: bit for bit the framework sequence (scale in fp32, round to fp16, sum over the
+    experts in fp32, round once) for top-2 routing, where the sum has two terms; rows of experts no token
+    selected are never read (they hold NaN here)."""
+    gen = torch.Generator(device=cuda).manual_seed(7 + tokens)
+    E, H = 8, 4096
+    logits = (torch.randn((tokens, E), generator=gen, device=cuda) * 2).half()
+    w, mask = ops.moe_route(logits, 2, want_mask=True)
+    y = (torch.randn((E, tokens, H), generator=gen, device=cuda) * 3).half()
+    want = torch.mul(y, w.t().unsqueeze(-1)).to(torch.float16).sum(0, dtype=torch.float32).to(torch.float16)
+    assert torch.equal(ops.moe_combine(y, w), want)
+    poisoned = y.clone()
+    poisoned[w.t() == 0] = float("nan")   # every (expert, token) row the token did not select
+    assert torch.equal(ops.moe_combine(poisoned, w), want)
+    # four selected experts: the fp32 sum of four terms in expert order, within an fp16 ulp of any other order
+    w4, _ = ops.moe_route(logits, 4)
+    got = ops.moe_combine(y, w4).float()
+    want4 = torch.mul(y, w4.t().unsqueeze(-1)).to(torch.float16).sum(0, dtype=torch.float32)
+    assert ((got - want4).abs() <= 2.0**-10 * want4.abs() + 1e-7).all()
+    with pytest.raises(ValueError):
+        ops.moe_combine(y, w[:, :4])
+    with pytest.raises(RuntimeError):
+        ops.moe_combine(y.float(), w)
+
+
+def test_mixtral_block_fused_routing_matches_operator_route(cuda):
+    """The block with routing and the weighted sum as one launch each against the same block on framework
+    operators: same GEMM launches, routing weights equal to a few fp32 ulps, hence outputs within an fp16 ulp."""
+    from test_experts_cpu import fill
+    from vllm_quick_amd.layers import experts as X
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    E, top_k, H, I = 8, 2, 128, 224
+    moe = X.MixtralMoE(E, top_k, H, I, linear_method=AWQConfig(4, 32, True).get_linear_method(),
+                       params_dtype=torch.float16)
+    fill(moe, seed=23)
+    moe = moe.to(cuda)
+    rng = np.random.default_rng(5)
+    with torch.inference_mode():
+        for tokens in (1, 3, 16, 70):
+            x = dev_t((rng.standard_normal((1, tokens, H)) * 0.5).astype(np.float16), cuda)
+            assert moe.fused_routing
+            fused = moe(x)
+            moe.fused_routing = False
+            plain = moe(x)
+            moe.fused_routing = True
+            assert not torch.isnan(fused).any()
+            tol = 2.0**-9 * plain.float().abs() + 2.0**-9 * plain.float().abs().max() * 1e-2 + 1e-6
+            assert ((fused.float() - plain.float()).abs() <= tol).all(), tokens

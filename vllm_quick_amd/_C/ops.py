@@ -278,11 +278,13 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
                             bias: Optional[torch.Tensor] = None,
                             cfg: Optional[Tuple[int, ...]] = None,
                             mask: Optional[torch.Tensor] = None,
-                            active_hint: int = 0) -> torch.Tensor:
+                            active_hint: int = 0,
+                            zero_masked: bool = True) -> torch.Tensor:
     """One launch for E GEMMs of one shape: in_feats [M, K] (shared by all problems) or [E, M, K] fp16,
     optional bias [E, N] -> [E, M, N] fp16.  Stands in for the reference's loop over experts
     (mixtral_quant.py:145-157).  `mask` (int32 [E] on the device, read by the kernel): problems whose entry
-    is 0 are skipped, their weights never read, and their rows of the result are zero; `active_hint` (how
+    is 0 are skipped, their weights never read, and their rows of the result are zero (`zero_masked=False`:
+    left as allocated, for a caller that never looks at them, one fill kernel less); `active_hint` (how
     many the caller expects to be on, 0 = unknown) steers the launch shape only."""
     _require(in_feats, torch.float16, "in_feats")
     E = packed.batch
@@ -307,7 +309,8 @@ def awq_gemm_packed_batched(in_feats: torch.Tensor,
         bias_ptr = bias.data_ptr()
     mask = _problem_mask(mask, E, x.device, cfg)
     with _on_device(x.device):
-        out = (torch.empty if mask is None else torch.zeros)((E, M, packed.N), dtype=torch.float16, device=x.device)
+        out = (torch.zeros if mask is not None and zero_masked else torch.empty)((E, M, packed.N), dtype=torch.float16,
+                                                                                 device=x.device)
         if M == 0:
             return out
         if (M * packed.K) % 8 and not shared:
@@ -336,7 +339,8 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
                                  bias: Optional[torch.Tensor] = None,
                                  cfg: Optional[Tuple[int, ...]] = None,
                                  mask: Optional[torch.Tensor] = None,
-                                 active_hint: int = 0) -> torch.Tensor:
+                                 active_hint: int = 0,
+                                 zero_masked: bool = True) -> torch.Tensor:
     """silu(x @ W[:, :N/2]) * (x @ W[:, N/2:]) in one launch: the merged gate_up projection of a gated
     MLP with its activation fused into the GEMM epilogue (llama.py:74-80 of the reference runs the GEMM,
     then `silu_and_mul`).  `packed` is a PackedAWQ ([M, K] -> [M, N/2]) or a PackedAWQBatch ([M, K] shared
@@ -368,8 +372,8 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
         raise ValueError("a problem mask needs a PackedAWQBatch")
     mask = _problem_mask(mask, E, x.device, cfg)
     with _on_device(x.device):
-        out = (torch.empty if mask is None else torch.zeros)((E, M, half) if batched else (M, half),
-                                                             dtype=torch.float16, device=x.device)
+        out = (torch.zeros if mask is not None and zero_masked else torch.empty)(
+            (E, M, half) if batched else (M, half), dtype=torch.float16, device=x.device)
         if M == 0:
             return out
         if batched and ((M * half) % 4 or (not shared and (M * packed.K) % 8)):
@@ -382,6 +386,49 @@ def awq_gemm_packed_silu_and_mul(in_feats: torch.Tensor,
         else:
             rc = lib.w4a16_gemm_packed_f16_ex(*head, mt, t, a, b, _stream())
         check(rc, "awq_gemm_silu_and_mul")
+    return out
+
+
+def moe_route(router_logits: torch.Tensor, top_k: int, first_local: int = 0, n_local: Optional[int] = None,
+              want_mask: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Routing weights of a Mixtral-style block in one launch (mixtral_quant.py:137-150: softmax over all
+    experts in fp32, top-k, renormalise, scatter): router_logits [T, E] fp16 -> weights [T, n_local] fp32 for
+    the experts [first_local, first_local + n_local) (0 where a token did not select the expert) and, with
+    `want_mask`, the int32 [n_local] problem mask of the batched launches (1 = some token selected it)."""
+    _require(router_logits, torch.float16, "router_logits")
+    if router_logits.dim() != 2:
+        raise ValueError(f"router_logits must be [tokens, experts], got {tuple(router_logits.shape)}")
+    T, E = router_logits.shape
+    n_local = E - first_local if n_local is None else n_local
+    logits = router_logits.contiguous()
+    with _on_device(logits.device):
+        weights = torch.empty((T, n_local), dtype=torch.float32, device=logits.device)
+        mask = torch.empty((n_local, ), dtype=torch.int32, device=logits.device) if want_mask else None
+        if T == 0:
+            return weights, None if mask is None else mask.zero_()
+        check(lib.w4a16_moe_route_f16(logits.data_ptr(), weights.data_ptr(), None if mask is None else mask.data_ptr(),
+                                      T, E, int(top_k), int(first_local), int(n_local), _stream()), "moe_route")
+    return weights, mask
+
+
+def moe_combine(y: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """out[t] = sum over experts e of fp16(y[e, t] * weights[t, e]), summed in fp32 and rounded once
+    (mixtral_quant.py:152-157), in one launch: y [E, T, H] fp16 (a batched launch's output), weights [T, E]
+    fp32 as `moe_route` returns them.  Experts with weight 0 for a token are not read."""
+    _require(y, torch.float16, "y")
+    _require(weights, torch.float32, "weights")
+    if y.dim() != 3 or tuple(weights.shape) != (y.shape[1], y.shape[0]):
+        raise ValueError(f"y must be [E, T, H] and weights [T, E], got {tuple(y.shape)} and {tuple(weights.shape)}")
+    if y.device != weights.device:
+        raise RuntimeError("y and weights are on different devices")
+    E, T, H = y.shape
+    y, weights = y.contiguous(), weights.contiguous()
+    with _on_device(y.device):
+        out = torch.empty((T, H), dtype=torch.float16, device=y.device)
+        if T == 0:
+            return out
+        check(lib.w4a16_moe_combine_f16(y.data_ptr(), weights.data_ptr(), out.data_ptr(), E, T, H, _stream()),
+              "moe_combine")
     return out
 
 

@@ -2878,6 +2878,9 @@ const char* w4a16_strerror(int code) {
 
 int w4a16_last_hip_error(void) { return g_last_hip_error; }
 
+// For the library's other source files (not exported): records the hipError_t of a failed launch.
+__attribute__((visibility("hidden"))) void w4a16_note_hip_error(int e) { g_last_hip_error = e; }
+
 int w4a16_abi_version(void) { return W4A16_ABI_VERSION; }
 
 #ifdef W4A16_STAMPS

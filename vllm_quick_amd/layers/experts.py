@@ -93,6 +93,9 @@ class MixtralMoE(torch.nn.Module):
         # one token selects top_k experts; 4 tokens of a top-2-of-8 router still leave a third of them idle,
         # beyond that the switch costs about what it saves
         self.sparse_max_tokens = 4
+        # routing weights and the weighted sum over experts as one launch each instead of fourteen framework
+        # kernels (GPU tensors only; the framework-operator route below stays for everything else)
+        self.fused_routing = True
         self._packed = None  # (quick stamp, w13 batch, w2 batch, full stamp)
         self._watched: List[torch.Tensor] = []
 
@@ -144,6 +147,23 @@ class MixtralMoE(torch.nn.Module):
         self._packed = ((write_epoch(), self.fuse_act, self._versions()), b13, b2, (stamp, self.fuse_act))
         return b13, b2
 
+    def _forward_fused(self, hidden_states: torch.Tensor, b13, b2) -> torch.Tensor:
+        """The block in four launches beside the gate: routing weights and problem mask, gate/up GEMM with the
+        activation, down GEMM, weighted sum over experts.  Same arithmetic as the framework-operator route in
+        `forward` (fp32 softmax / top-k / renormalise; each expert's output scaled in fp32 and rounded to fp16,
+        the sum over experts in fp32 and rounded once), so one module gives the same values whichever route a
+        call takes, up to the last bit of the fp32 routing weights (this kernel's `expf` and summation order
+        against the framework's)."""
+        router_logits, _ = self.gate(hidden_states)
+        sparse = hidden_states.shape[0] <= self.sparse_max_tokens
+        E = len(self.expert_indicies)
+        weights, mask = ops.moe_route(router_logits, self.top_k, self.expert_indicies[0], E, want_mask=sparse)
+        on = min(E, self.top_k * hidden_states.shape[0]) if sparse else 0
+        # masked-out experts' rows are never read (their routing weight is 0 for every token): no fill needed
+        act = ops.awq_gemm_packed_silu_and_mul(hidden_states, b13, mask=mask, active_hint=on, zero_masked=False)
+        y = ops.awq_gemm_packed_batched(act, b2, mask=mask, active_hint=on, zero_masked=False)  # [E, T, H]
+        return tensor_model_parallel_all_reduce(ops.moe_combine(y, weights))
+
     def routing(self, hidden_states: torch.Tensor) -> torch.Tensor:
         """[tokens, local experts] fp32 weights: softmax, top-k, renormalise (mixtral_quant.py:137-150)."""
         router_logits, _ = self.gate(hidden_states)
@@ -158,8 +178,10 @@ class MixtralMoE(torch.nn.Module):
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         batch_size, sequence_length, hidden_dim = hidden_states.shape
         hidden_states = hidden_states.view(-1, hidden_dim)
-        expert_weights = self.routing(hidden_states)  # [T, E_local]
         batches = self._batches() if self.batched else None
+        if batches is not None and self.fused_routing and self.fuse_act and hidden_states.is_cuda:
+            return self._forward_fused(hidden_states, *batches).view(batch_size, sequence_length, hidden_dim)
+        expert_weights = self.routing(hidden_states)  # [T, E_local]
         if batches is None:
             # the reference's loop (mixtral_quant.py:145-157), with the sum over experts kept in fp32 and
             # rounded once like the batched route below, so that one module gives the same values whichever
