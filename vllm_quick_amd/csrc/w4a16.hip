@@ -2568,6 +2568,9 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
     const int streams = t * waves;
     depth = (streams < 24 || (streams < 32 && a.K >= 6144) ||
              (streams == 32 && waves == 16 && (a.M > kDecodeMaxRows || a.K >= 12800))) ? 2 : 1;
+    // 4 tiles x 4 waves (several workgroups to a CU): one block up to K = 6144 (4096 x 28672 at 1 row 14.0 us
+    // against 14.9), two beyond (8 x 14336 x 4096: 46.6 against 52.2)
+    if (t == 4 && waves == 4 && a.K < 6144) depth = 1;
   }
 #define X(T_, W_)                                                                                     \
   if (t == T_ && waves == W_)                                                                         \
@@ -2794,6 +2797,13 @@ Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool 
       if (best < 0 || load < best) best = load, c.t = order[i];
     }
   }
+  // From six tiles per CU on (very wide layers, batched launches): 4-wave workgroups of 4 tiles, several to a CU,
+  // at every row count; the streaming kernel's preferences (2 tiles up to 4 rows, 8 x 8 from 9 rows with the fused
+  // activation) do not carry over: 4096 x 28672 at 1 row 14.0 us against 15.0 with 2 tiles, with the fused
+  // activation 13.2 against 14.9; 8 x (14336 x 4096) at 1 row 46.6 against over 56; 8 x (4096 x 28672) with the
+  // fused activation at 16 rows 97 against 106 for 8 x 8.
+  if ((long long)probe.NT * batch >= 6 * 256 && ((c.a == 4 && (c.t == 2 || c.t == 4)) || (act && c.a == 8 && c.t == 8)))
+    c.t = 4, c.a = 4;
   if (!decode_built(c.t, c.a, act)) return c;
   const int per_wg = act ? c.t / 2 : c.t;
   const int nb_max = ceil_div(probe.KB, c.a);
