@@ -179,6 +179,76 @@ static int check_case(int M, int K, int N, int G, bool with_bias) {
   return fails;
 }
 
+// Expert routing and the weighted sum over experts against a host restatement of
+// vllm/model_executor/models/mixtral_quant.py:137-157 (softmax in fp32, top-2, renormalise; each expert's
+// output scaled and rounded to fp16, the sum taken in fp32 and rounded once).
+static int check_routing(int tokens, int n_experts, int first, int n_local, int hidden) {
+  const int top_k = 2;
+  std::vector<uint16_t> logits((size_t)tokens * n_experts), y((size_t)n_local * tokens * hidden);
+  for (auto& v : logits) v = awq_c_f2h(2.0f * normal());
+  for (auto& v : y) v = awq_c_f2h(3.0f * normal());
+  std::vector<float> want_w((size_t)tokens * n_local, 0.f);
+  std::vector<int> want_mask(n_local, 0);
+  for (int t = 0; t < tokens; ++t) {
+    std::vector<float> p(n_experts);
+    float mx = -INFINITY, sum = 0.f;
+    for (int e = 0; e < n_experts; ++e) mx = std::fmax(mx, p[e] = awq_c_h2f(logits[(size_t)t * n_experts + e]));
+    for (int e = 0; e < n_experts; ++e) sum += p[e] = std::exp(p[e] - mx);
+    for (int e = 0; e < n_experts; ++e) p[e] /= sum;
+    int a = 0;
+    for (int e = 1; e < n_experts; ++e) if (p[e] > p[a]) a = e;
+    int b = a == 0 ? 1 : 0;
+    for (int e = 0; e < n_experts; ++e) if (e != a && p[e] > p[b]) b = e;
+    for (int e : {a, b})
+      if (e >= first && e < first + n_local) {
+        want_w[(size_t)t * n_local + e - first] = p[e] / (p[a] + p[b]);
+        want_mask[e - first] = 1;
+      }
+  }
+  uint16_t* d_logits = to_device(logits);
+  uint16_t* d_y = to_device(y);
+  float* d_w = nullptr;
+  int* d_mask = nullptr;
+  uint16_t* d_out = nullptr;
+  HIP_OK(hipMalloc(&d_w, want_w.size() * 4));
+  HIP_OK(hipMalloc(&d_mask, n_local * 4));
+  HIP_OK(hipMalloc(&d_out, (size_t)tokens * hidden * 2));
+  int fails = 0;
+  int rc = w4a16_moe_route_f16(d_logits, d_w, d_mask, tokens, n_experts, top_k, first, n_local, nullptr);
+  if (rc == W4A16_OK) rc = w4a16_moe_combine_f16(d_y, d_w, d_out, n_local, tokens, hidden, nullptr);
+  if (rc != W4A16_OK) {
+    std::printf("FAIL routing: %s (hip error %d)\n", w4a16_strerror(rc), w4a16_last_hip_error());
+    return 1;
+  }
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<float> w(want_w.size());
+  std::vector<int> mask(n_local);
+  std::vector<uint16_t> out((size_t)tokens * hidden);
+  HIP_OK(hipMemcpy(w.data(), d_w, w.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(mask.data(), d_mask, n_local * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out.data(), d_out, out.size() * 2, hipMemcpyDeviceToHost));
+  size_t bad_w = 0, bad_mask = 0, bad_out = 0;
+  for (size_t i = 0; i < w.size(); ++i)
+    bad_w += ((w[i] == 0.f) != (want_w[i] == 0.f)) || std::fabs(w[i] - want_w[i]) > 2e-6f * want_w[i] + 1e-9f;
+  for (int e = 0; e < n_local; ++e) bad_mask += mask[e] != want_mask[e];
+  // the sum over experts from the DEVICE's weights: two terms, so bit-exact whatever the order
+  for (int t = 0; t < tokens; ++t)
+    for (int h = 0; h < hidden; ++h) {
+      float acc = 0.f;
+      for (int e = 0; e < n_local; ++e) {
+        const float we = w[(size_t)t * n_local + e];
+        if (we != 0.f) acc += awq_c_h2f(awq_c_f2h(awq_c_h2f(y[((size_t)e * tokens + t) * hidden + h]) * we));
+      }
+      bad_out += out[(size_t)t * hidden + h] != awq_c_f2h(acc);
+    }
+  fails = (bad_w || bad_mask || bad_out) ? 1 : 0;
+  std::printf("%s routing + weighted sum  tokens=%d experts=%d local=[%d,%d) hidden=%d: %zu weights, %zu mask entries, "
+              "%zu outputs differ\n", fails ? "FAIL" : "ok  ", tokens, n_experts, first, first + n_local, hidden, bad_w,
+              bad_mask, bad_out);
+  for (void* p : {(void*)d_logits, (void*)d_y, (void*)d_w, (void*)d_mask, (void*)d_out}) HIP_OK(hipFree(p));
+  return fails;
+}
+
 int main() {
   if (w4a16_abi_version() != W4A16_ABI_VERSION) {
     std::printf("FAIL ABI version %d, header says %d\n", w4a16_abi_version(), W4A16_ABI_VERSION);
@@ -190,6 +260,8 @@ int main() {
   fails += check_case(7, 384, 200, 64, true);
   fails += check_case(40, 640, 416, 32, false);
   fails += check_case(130, 1024, 1376, 128, true);
+  fails += check_routing(1, 8, 0, 8, 256);
+  fails += check_routing(37, 8, 4, 4, 512);
   std::printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
   return fails ? 1 : 0;
 }
