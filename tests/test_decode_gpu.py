@@ -316,3 +316,25 @@ def test_linear_method_split_k_option(ops, cuda):
     ws = ops.stream_workspace(cuda)
     assert ws is not None and ws.numel() == 1 << 20 and ops.stream_workspace(cuda) is ws
     assert int(ws[:65536].view(torch.int32).abs().max().item()) == 0
+
+
+@pytest.mark.parametrize("N,shape_1,shape_16", [(13824, "<4,8>", "<4,8>"), (22016, "<6,8>", "<6,8>"), (28672, "<4,4>", "<4,4>")])
+def test_wide_layers_take_their_decode_shapes(L, ops, cuda, N, shape_1, shape_16):
+    """Three to six column tiles per CU run one workgroup per CU (4 or 6 tiles x 8 waves), more than six run
+    4-wave workgroups of 4 tiles: the library's own choice on layers that wide (K kept short for the oracle),
+    plain and with the fused activation, at 1, 4, 9 and 16 rows."""
+    K, G = 1024, 128
+    assert L.launch_shape(1, K, N) == "gemm_decode_kernel" + shape_1
+    assert L.launch_shape(16, K, N) == "gemm_decode_kernel" + shape_16
+    x16, qw, s, qz = orc.make_inputs(16, K, N, G, seed=N)
+    packed = ops.awq_repack(*[dev_t(a, cuda) for a in (qw, s, qz)])
+    for M in (1, 4, 9, 16):
+        x = x16[:M]
+        want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
+        y = ops.awq_gemm_packed(dev_t(x, cuda), packed)
+        assert_parity(y.cpu().numpy(), want, exact, f"N={N} M={M}")
+        assert L.launch_shape(M, K, N, 1, 1).startswith("gemm_decode_kernel")
+        got = ops.awq_gemm_packed_silu_and_mul(dev_t(x, cuda), packed).float().cpu().numpy().astype(np.float64)
+        ref, g, u = oracle_act(x, qw, s, qz, None)
+        err = np.abs(got - ref.astype(np.float64))
+        assert (err <= act_bound(g, u)).all(), (N, M, float((err - act_bound(g, u)).max()))

@@ -201,6 +201,10 @@ def test_every_launch_shape(abi, L, cuda, G):
                 continue  # covered at 10 blocks
             y = abi.gemm_packed(tx, packed, cfg=cfg)
             assert_parity(y.cpu().numpy(), want, exact, strict=True, what=f"G={G} K={K} cfg={cfg}")
+            if len(cfg) == 3 and cfg[0] == 1:
+                # the streaming kernel's compact reduction for up to 4 rows (one wave finishes every tile)
+                y3 = abi.gemm_packed(tx[:3].contiguous(), packed, cfg=cfg)
+                assert_parity(y3.cpu().numpy(), want[:3], exact[:3], strict=True, what=f"G={G} K={K} cfg={cfg} M=3")
         if K == 1280:
             for m in (3, 20, M):  # the three launch shapes of the stock-layout kernel at this group size
                 assert_parity(abi.gemm_stock(tx[:m].contiguous(), tqw, ts, tqz).cpu().numpy(), want[:m], exact[:m],

@@ -506,28 +506,30 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
     }
     __syncthreads();
     if (w != 0) return;
-    const int item = lane;  // (tile or tile pair, token, column group)
-    const int ti = item / 16, tok = (item >> 2) & 3, grp = item & 3;
-    if (ti >= OUTS || tok >= a.M) return;
-    f32x4 v = red[(ti * 4 + tok) * 4 + grp];
+    // item = (tile or tile pair, token, column group): 16 per tile, 64 per pass of the wave
+    for (int item = lane; item < OUTS * 16; item += 64) {
+      const int ti = item / 16, tok = (item >> 2) & 3, grp = item & 3;
+      if (tok >= a.M) continue;
+      f32x4 v = red[(ti * 4 + tok) * 4 + grp];
 #pragma unroll
-    for (int s = 1; s < W; ++s) v += red[((s * T + ti) * 4 + tok) * 4 + grp];
-    f32x4 vu = v;
-    if constexpr (ACT) {
-      vu = red[((ti + H) * 4 + tok) * 4 + grp];
+      for (int s = 1; s < W; ++s) v += red[((s * T + ti) * 4 + tok) * 4 + grp];
+      f32x4 vu = v;
+      if constexpr (ACT) {
+        vu = red[((ti + H) * 4 + tok) * 4 + grp];
 #pragma unroll
-      for (int s = 1; s < W; ++s) vu += red[((s * T + ti + H) * 4 + tok) * 4 + grp];
-    }
-    const int nt = nt0 + ti, n = nt * 16 + grp * 4, m = m0 + tok;
-    if constexpr (ACT) {
-      const int NH = a.N / 2;
-      if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
-    } else {
-      if (nt < a.NT && n < a.N) {
-        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
-        f16x4 hv = finish(v, n);
-        if (a.add_out) hv = *dst + hv;
-        *dst = hv;
+        for (int s = 1; s < W; ++s) vu += red[((s * T + ti + H) * 4 + tok) * 4 + grp];
+      }
+      const int nt = nt0 + ti, n = nt * 16 + grp * 4, m = m0 + tok;
+      if constexpr (ACT) {
+        const int NH = a.N / 2;
+        if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+      } else {
+        if (nt < a.NT && n < a.N) {
+          f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+          f16x4 hv = finish(v, n);
+          if (a.add_out) hv = *dst + hv;
+          *dst = hv;
+        }
       }
     }
     return;
