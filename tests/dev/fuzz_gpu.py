@@ -58,7 +58,11 @@ while time.time() - t0 < budget:
         G = 128
         K, N = [(4096, 1376), (4096, 2752), (11008, 4096), (4096, 4096), (2048, 11008), (4096, 5504)][rng.integers(6)]
     M = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 200, 300]))
-    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched", "cfg", "cfg", "act_cfg"])
+    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched", "cfg", "cfg", "act_cfg", "decode", "decode"])
+    if mode == "decode":  # the decode kernel with a forced shape: up to 16 rows, whole 128-k blocks
+        M = int(rng.integers(1, 17))
+        K = 128 * int(rng.integers(1, 40)) if G <= 128 else G * int(rng.integers(1, 20))
+        N = 16 * int(rng.integers(1, 60))
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
     what = f"{mode} M={M} K={K} N={N} G={G}"
     try:
@@ -83,6 +87,17 @@ while time.time() - t0 < budget:
                 y = ops.awq_gemm_packed(t(x), pk, cfg=cfg)
             except ValueError:
                 continue  # shape/launch combination the library refuses (e.g. K blocks not divisible by kw)
+            ok = close(y.float().cpu().numpy(), want, exact, what)
+        elif mode == "decode":
+            from vllm_quick_amd import _lib
+            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
+            shapes = _lib.built_shapes(4)
+            tt, ww, _ = shapes[rng.integers(len(shapes))]
+            splits = int(rng.integers(1, 5)) if M <= 4 and tt <= 4 else 1
+            cfg = ("decode", int(tt), int(ww), splits, int(rng.integers(0, 3)))
+            what += f" cfg={cfg}"
+            pk = ops.awq_repack(t(qw), t(s), t(qz))
+            y = ops.awq_gemm_packed(t(x), pk, cfg=cfg, workspace=ops.gemm_workspace(dev) if splits > 1 else None)
             ok = close(y.float().cpu().numpy(), want, exact, what)
         elif mode == "batched":
             E = int(rng.integers(2, 5))
