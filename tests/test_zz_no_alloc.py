@@ -83,6 +83,21 @@ def test_static_scratch_entry_point_rejects_what_does_not_fit(L, cuda):
     # 65 rows are not a decode-kernel problem: no launch shape of this entry point serves them
     x65 = dev_t(orc.make_inputs(65, K, N, 128, seed=2)[0], cuda)
     call(L, cuda, True, x65, pw, ps, K, N, 128, 0, 0, 0, expect=-5)
+    # the fused activation takes tile PAIRS: one tile (and any odd count) is no launch shape, with a K split or
+    # without, and is refused before anything is computed from "tiles per workgroup"
+    K2, N2 = 1024, 512
+    x1, qw2, s2, qz2 = orc.make_inputs(1, K2, N2, 128, seed=3)
+    tx1, tqw2, ts2, tqz2 = [dev_t(a, cuda) for a in (x1, qw2, s2, qz2)]
+    pw2 = torch.empty(L.lib.w4a16_packed_weight_bytes(K2, N2), dtype=torch.uint8, device=cuda)
+    ps2 = torch.empty(L.lib.w4a16_packed_sz_bytes(K2, N2, 128), dtype=torch.uint8, device=cuda)
+    assert L.lib.w4a16_repack(tqw2.data_ptr(), ts2.data_ptr(), tqz2.data_ptr(), pw2.data_ptr(), ps2.data_ptr(), K2, N2,
+                              128, torch.cuda.current_stream().cuda_stream) == 0
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=cuda)
+    for t in (1, 3):
+        for splits in (1, 2):
+            assert L.lib.w4a16_decode_workspace_bytes(K2, N2, 1, 1, t, 8, splits) == 0
+            call(L, cuda, True, tx1, pw2, ps2, K2, N2, 128, t, 8, splits, epilogue=1, expect=-5)
+            call(L, cuda, False, tx1, pw2, ps2, K2, N2, 128, t, 8, splits, ws, epilogue=1, expect=-5)
     # and a split that fits runs
     got = call(L, cuda, True, tx, pw, ps, K, N, 128, 2, 8, 2)
     f = orc.gemm_faithful(x, qw, s, qz).astype(np.float64)

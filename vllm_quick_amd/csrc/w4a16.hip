@@ -2494,6 +2494,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   constexpr bool kPlain = T <= 8;
   constexpr bool kAct = T % 2 == 0 && T / 2 <= 8;
   if (!decode_ok(a) || (act && a.N % 32)) return W4A16_E_SHAPE;
+  if (act ? !kAct : !kPlain) return W4A16_E_SHAPE;  // (before any division by tiles per workgroup: T / 2 is 0 for T = 1)
   if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
   const bool xlds = a.M <= kDecodeMaxRows;
   if (!xlds && splits > 1) return W4A16_E_SHAPE;  // the K split is built for up to 4 rows
@@ -3123,6 +3124,7 @@ int w4a16_gemm_packed_f16_decode_cfg(const void* x, long long x_batch_stride, co
 size_t w4a16_decode_workspace_bytes(int K, int N, int batch, int epilogue, int t, int waves, int splits) {
   if (K <= 0 || N <= 0 || batch <= 0 || t <= 0 || waves <= 0 || splits <= 1 || splits > kMaxSplits) return 0;
   const bool act = epilogue == W4A16_EPI_SILU_MUL;
+  if (!decode_built(t, waves, act)) return 0;  // (the fused activation takes tile pairs: no odd t, so t / 2 >= 1 below)
   const int KB = ceil_div(K, 128);
   splits = ceil_div(KB, ceil_div(KB, splits));
   const int NT = ceil_div(N, 16);
