@@ -241,12 +241,31 @@ int w4a16_gemm_packed_f16_decode_cfg(const void* x, long long x_batch_stride, co
 size_t w4a16_decode_workspace_bytes(int K, int N, int batch, int epilogue, int t, int waves, int splits);
 
 /*
+ * The 32x32x16 kernel with private slabs (w4a16_gemm_packed_f16_wide_cfg, kw > 0) with K split over `splits`
+ * workgroups per output tile, for tuning and tests (w4a16_gemm_packed_f16_ws picks it by itself for 97-128 rows):
+ * every workgroup of a tile leaves its fp32 partial sums in its own slot of `workspace`, draws a ticket, and the
+ * one that arrives last adds the slots in split order and stores, so the result does not depend on timing.
+ * With two workgroups per tile a 128-row x 96-column tile (mt = 4, t = 3, kw = 4) fills the chip on the
+ * 4096 x 11008 layer at 128 rows, and one converted weight fragment feeds four matrix instructions instead of two.
+ * splits > 1 needs a 4-wave shape and a `workspace` (16-byte aligned) of w4a16_wide_workspace_bytes(...) bytes,
+ * zero before its first use; same rules for the buffer as for w4a16_gemm_packed_f16_decode_cfg, whose buffer it
+ * may share.  Epilogues as for w4a16_gemm_packed_f16_ex (one problem).  No counterpart in the reference, whose
+ * split over K goes through a [split_k, M, N] fp16 tensor and a separate sum (gemm_kernels.cu:420-445).
+ */
+int w4a16_gemm_packed_f16_wide_split_cfg(const void* x, const void* packed_w, const void* packed_sz, const void* bias,
+                                         void* out, int M, int K, int N, int G, int epilogue, int mt, int t, int kw,
+                                         int splits, void* workspace, size_t workspace_bytes, void* stream);
+size_t w4a16_wide_workspace_bytes(int M, int N, int batch, int epilogue, int mt, int t, int splits);
+
+/*
  * w4a16_gemm_packed_f16_ex with the library's launch shape and an optional workspace (NULL: exactly
  * w4a16_gemm_packed_f16_ex with mt == 0).  With a workspace of at least w4a16_workspace_bytes(...) bytes the
  * library may split K over workgroups where the plain launch would leave most of the chip idle (few columns,
- * long K, up to 4 rows: the per-rank qkv projection of a tensor-parallel model at decode).  Same rules for the
+ * long K, up to 4 rows: the per-rank qkv projection of a tensor-parallel model at decode) or short of matrix
+ * work per converted weight (97-128 rows: 128-row tiles, two workgroups per tile).  Same rules for the
  * buffer as above; a buffer that is too small is ignored.  w4a16_workspace_bytes returns 0 where no split is
- * chosen.  w4a16_launch_shape_ws reports the choice made with a workspace (W4A16_KERNEL_DECODE: (1, t, waves, splits)).
+ * chosen.  w4a16_launch_shape_ws reports the choice made with a workspace (W4A16_KERNEL_DECODE: (1, t, waves,
+ * splits); W4A16_KERNEL_MFMA32: (mt, t, splits, kw)).
  */
 size_t w4a16_workspace_bytes(int M, int K, int N, int G, int batch, int epilogue);
 int w4a16_gemm_packed_f16_ws(const void* x, long long x_batch_stride, const void* packed_w, const void* packed_sz,
@@ -281,7 +300,8 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
  *   shape[0]  kernel: one of W4A16_KERNEL_*
  *   shape[1..4]  STREAMING   (mt, t, waves, 0)      16-row / 16-column tiles, `waves` wavefronts split K
  *                LDS_STAGED  (mt, t, nw, kw)        16-row / 16-column tiles
- *                MFMA32      (mt, t, 1, kw)         32-row / 32-column tiles, private slabs per wavefront
+ *                MFMA32      (mt, t, splits, kw)    32-row / 32-column tiles, private slabs per wavefront
+ *                                                   (splits = 1 unless a workspace lets K be split over workgroups)
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
  *                DECODE      (1, t, waves, splits)  up to 16 rows
  */

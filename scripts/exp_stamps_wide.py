@@ -9,21 +9,25 @@ from vllm_quick_amd._C import ops
 from bench import make_weights, make_x
 
 dev = torch.device("cuda:0")
-mt, t, kw = (int(v) for v in sys.argv[1].split(","))
+mt, t, kw, *rest = (int(v) for v in sys.argv[1].split(","))
+splits = rest[0] if rest else 1
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 K, N, G = 4096, 11008, 128
 if len(sys.argv) > 4:
     K, N = int(sys.argv[3]), int(sys.argv[4])
 packs = [ops.awq_repack(*make_weights(K, N, G, i, dev)) for i in range(16)]
 x = make_x(M, K, 1, dev)
+ws = ops.gemm_workspace(dev, 32 << 20)
 for rep in range(40):   # warm clocks, rotate weights so HBM is really read
     for p in packs:
-        ops.awq_gemm_packed(x, p, cfg=("wide", mt, t, kw))
+        ops.awq_gemm_packed(x, p, cfg=("wide", mt, t, kw, splits), workspace=ws)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 slices = -(-(-(-N // 32)) // t)
 mblocks = -(-M // (mt * 32))
-ctas = ((slices + 7) // 8) * 8 * mblocks
+ctas = ((slices * mblocks + 7) // 8) * 8
+if splits > 1:
+    print("(K split: stamps of the workgroups of split 0 and 1 overwrite each other per blockIdx.x; whichever wrote last is shown)")
 buf = np.zeros(4096 * 32, dtype=np.uint64)
 rc = lib.w4a16_dbg_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
 assert rc == 0, rc
@@ -39,7 +43,12 @@ clk = (st[:, 23] - st[:, 0]) / np.maximum(st[:, 31] - st[:, 30], 1) * 100.0
 stat("clock MHz (cycles / 100 MHz ticks)", clk)
 stat("start skew", st[:, 0] - t0)
 stat("setup + first requests", st[:, 1] - st[:, 0])
-nblk = -(-(-(-K // 128)) // kw)
+stat("  entry -> work item known", st[:, 24] - st[:, 0])
+stat("  -> offsets, accumulators zeroed", st[:, 25] - st[:, 24])
+stat("  -> first weight block requested", st[:, 26] - st[:, 25])
+stat("  -> half slab 0 requested", st[:, 27] - st[:, 26])
+stat("  -> half slab 1 requested", st[:, 1] - st[:, 27])
+nblk = -(-(-(-(-(-K // 128)) // splits)) // kw)
 prev = st[:, 1]
 for b in range(min(nblk, 16)):
     cur = st[:, 2 + b]

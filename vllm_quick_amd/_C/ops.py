@@ -198,8 +198,18 @@ def awq_gemm_packed(in_feats: torch.Tensor,
                                                       packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), 0, M,
                                                       packed.K, packed.N, packed.G, 1, 0, t, waves, depth, splits, ws_ptr,
                                                       ws_bytes, _stream())
+        elif cfg[0] == "wide" and len(cfg) > 4 and cfg[4] > 1:  # ("wide", mt, t, kw, splits): K split over workgroups
+            _, mt, t, kw, splits = cfg
+            if workspace is None:
+                workspace = gemm_workspace(x.device, lib.w4a16_wide_workspace_bytes(M, packed.N, 1, 0, mt, t, splits))
+            _check_workspace(workspace, x.device)
+            rc = lib.w4a16_gemm_packed_f16_wide_split_cfg(x.data_ptr(), packed.packed_w.data_ptr(),
+                                                          packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M,
+                                                          packed.K, packed.N, packed.G, 0, mt, t, kw, splits,
+                                                          workspace.data_ptr(),
+                                                          workspace.numel() * workspace.element_size(), _stream())
         elif cfg[0] == "wide":  # the 32x32x16 kernel: ("wide", mt, t, kw), tiles of 32 rows / 32 columns
-            _, mt, t, kw = cfg
+            _, mt, t, kw = cfg[:4]
             rc = lib.w4a16_gemm_packed_f16_wide_cfg(x.data_ptr(), packed.packed_w.data_ptr(),
                                                     packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M,
                                                     packed.K, packed.N, packed.G, mt, t, kw, _stream())

@@ -47,6 +47,8 @@ SYMBOLS = {
     "w4a16_gemm_packed_f16_decode_cfg": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                          [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     "w4a16_decode_workspace_bytes": (c_size_t, [c_int] * 7),
+    "w4a16_gemm_packed_f16_wide_split_cfg": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "w4a16_wide_workspace_bytes": (c_size_t, [c_int] * 7),
     "w4a16_workspace_bytes": (c_size_t, [c_int] * 6),
     "w4a16_gemm_packed_f16_ws": (c_int, [c_void_p, ctypes.c_longlong] + [c_void_p] * 4 + [ctypes.c_longlong] +
                                  [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,524 @@
+// libw4a16.so: the 32x32x16 GEMM kernel with private activation slabs (K split over the waves of a workgroup)
+// and its launcher.  Layout, arithmetic and the kernel families are described at the top of w4a16.hip.
+
+#include "w4a16_common.h"
+
+namespace W4A16_HIDDEN w4a16 {
+namespace {
+
+// ---------------------------------------------------------------------------
+// GEMM on the private layout with 32x32x16 matrix instructions (M > 32)
+// ---------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16 does twice the work of the 16x16x32 form per instruction and per converted
+// weight word, which halves the int4 -> fp16 conversion's share of the vector issue slots.  Its A
+// operand wants lane l to hold 8 k of weight column l & 31, k-octet l >> 5 of a 16-k step.  The packed
+// layout (16-column tiles, lane quads of four 32-k words) serves it as it is: lanes with bit 4 clear
+// read the even 16-column tile of the pair, the others the odd one, from source lanes
+// (l & 15) + 16 (2 s + (l >> 5)), s = 0, 1: two 16-byte loads per lane and 128-k block, word j of load
+// s being the fragment of k-step 2 j + s (k = 128 kb + 32 j + 16 s + 8 (l >> 5) + i).
+//
+// A workgroup owns MT x T tiles of 32 x 32 outputs over the whole of K; its KW waves split K (wave w
+// takes blocks w, w + KW, ...) and each holds all MT x T accumulator tiles.  A wave keeps the
+// [32 MT rows] x [128 k] activation slab of its current block in a PRIVATE piece of LDS: two halves of
+// 64 k, each row of a half 128 bytes with its 16-byte chunks XOR-swizzled by the row.  The halves are
+// filled by LDS-DMA loads (global -> LDS with no register in between; the swizzle is applied to the
+// source address, since a DMA instruction writes 1 KiB of LDS in lane order): as soon as the k-steps of
+// a half are done, the same half of the wave's NEXT block is requested into it and has the other
+// half's k-steps to arrive.  No other wave touches that LDS, so the main loop has no barrier; the
+// DMA's completion is awaited with counted s_waitcnt vmcnt (vector-memory operations of a wave complete
+// in issue order; the compiler does not track data that arrives in LDS this way).
+template <int MT, int T, int KW, int SZS, bool ACT = false>
+__global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_blocks, int panel_rows,
+                                                            const GemmArgs ga, const WideSplit sp) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  fetch_args_now(ga);
+  asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows), "s"(sp.ws), "s"(sp.tickets), "s"(sp.kb_per_split));
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
+  const GemmArgs a = batch_slice(ga);
+  constexpr int R = MT * 32;             // rows of the workgroup's tile
+  constexpr int HALF = R * 128;          // bytes of a half slab: R rows x 64 k
+  constexpr int SLAB = 2 * HALF;         // LDS per wave
+  constexpr int XLR = R / 8;             // DMA loads per half slab (8 rows x 128 bytes each)
+  constexpr int XL = (W4A16_DBG & 1) ? 1 : XLR;
+  constexpr int NSZ = 4 / SZS;           // scale/zero words per 128-k block and tile
+  constexpr int WL = T * (NSZ + 2);      // register loads per weight block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+#ifdef W4A16_STAMPS
+  constexpr int NWAVES = KW;
+  int n_done = 0;
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
+  STAMP(0);
+
+  // workgroup id -> (column slice, row block): row blocks of a slice share an XCD (ids 8 apart), in
+  // panels once there are more than 8 of them (as gemm_tiled_kernel)
+  int slice, mb;
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
+  STAMP(24);
+  // A 32-column tile of the matrix instruction is two 16-column tiles of the packed layout: normally neighbours.
+  // With the fused activation the weights are [gate | up] (N / 2 columns each, whole 16-column tiles) and tile
+  // j of the workgroup is made of gate columns 16 j .. 16 j + 15 and the SAME columns of the up half, so that a
+  // lane holds both operands of silu(gate) * up for its columns (accumulator registers 8 apart).
+  const int ct0 = slice * T;  // first tile
+  const int m0 = mb * R;
+  auto tile16 = [&](int t) {
+    const int second = (lane >> 4) & 1;
+    if constexpr (ACT) {
+      const int nth = a.NT / 2;  // 16-column tiles per half
+      return min(ct0 + t, nth - 1) + second * nth;
+    }
+    // 16-column tiles past the end re-read the last one (valid memory); their results are dropped
+    return min(2 * (ct0 + t) + second, a.NT - 1);
+  };
+
+  // Per-lane byte offsets from the (uniform) buffer bases: 32 bits each (the host checks the sizes).
+  uint32_t woff[T], szoff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int t16 = tile16(t);
+    woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
+    szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
+  }
+  // DMA p of a half slab fills rows 8 p .. 8 p + 7: lane -> row 8 p + (lane >> 3), 16-byte position
+  // lane & 7, which holds chunk (lane & 7) ^ ((row >> 1) & 7) of the row's 64 k
+  uint32_t xoff[XLR];
+  int xchunk[2];  // chunk index fetched by this lane, p even / odd
+#pragma unroll
+  for (int e = 0; e < 2; ++e) xchunk[e] = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);
+#pragma unroll
+  for (int p = 0; p < XLR; ++p)
+    xoff[p] = ((uint32_t)min(m0 + 8 * p + (lane >> 3), a.M - 1) * a.K + xchunk[p & 1] * 8) * 2u;
+  const int wbase = w * SLAB;
+  // B fragment of k-step ks (0..3) of a half: row r32 (+ 32 mt), chunk 2 ks + h
+  int xrd[4];
+  {
+    const int f = (r32 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xrd[ks] = wbase + r32 * 128 + (((2 * ks + h) ^ f) << 4);
+  }
+
+  f32x16 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  const DqConst dqc = make_dq_const();
+  STAMP(25);
+
+  struct WSet {
+    uint32_t sz[T][NSZ];
+    u32x4 q[T][2];
+  };
+  // Buffer-addressed loads throughout: descriptor base + 32-bit lane offset + scalar offset costs no
+  // vector arithmetic per load, and (unlike the global_load ... lds form, which the compiler treats as a
+  // flat access that forces every later wait to zero) the LDS-DMA variant keeps the compiler's own wait
+  // counts for the weight registers exact.
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  auto load_w = [&](int kb, WSet& b) {
+    if (W4A16_DBG & 2) kb = w;  // ablation: weights from cache
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
+        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
+      b.q[t][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + 512, kb * 1024, 0);
+    }
+  };
+  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
+  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
+  auto dma_x = [&](int kb, int hp) {
+#pragma unroll
+    for (int p = 0; p < XL; ++p)  // (ablation 1: XL is 1, an eighth of the activation traffic)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + wbase + hp * HALF + p * 1024), 16, xoff[p],
+          (kb * 128 + hp * 64) * 2, 0, 0);
+  };
+  // B fragments of k-step `kstep` (0..7) of the block: 2 ds_read_b128 from half kstep / 4
+  auto read_x = [&](int kstep, f16x8 (&xf)[MT]) {
+    const int hp = kstep >> 2, ks = kstep & 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + hp * HALF + mt * 4096);
+  };
+  // The weight fragment of tile t at k-step `kstep` (scale/zero constants refreshed where a new group starts)
+  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+    if (W4A16_DBG & 4) return __builtin_bit_cast(f16x8, b.q[t][kstep & 1]);  // ablation: no conversion
+    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+  };
+  // One k-step: MT x T matrix instructions.  The conversion runs ONE TILE AHEAD of them (`af0` comes in
+  // converted; tiles 1.. and tile 0 of the next k-step are converted here), and the two instruction kinds
+  // are dealt out alternately: a wave issues in order, so a matrix instruction that finds the pipe still
+  // busy with its predecessor would otherwise hold back the ~52 cycles of conversion behind it, and a
+  // single wave would run at half the matrix rate.
+  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
+    f16x8 af[T + 1];
+    af[0] = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T)
+        af[t + 1] = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        af[T] = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+    }
+    if (kstep + 1 < 8) af0 = af[T];
+    {
+      constexpr int per = (13 + MT - 1) / MT;  // vector instructions of one conversion per matrix instruction
+#pragma unroll
+      for (int i = 0; i < T * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one matrix instruction
+        __builtin_amdgcn_sched_group_barrier(0x002, per, 0);  // a share of the next conversion
+      }
+    }
+  };
+  // One 128-k block from weight set `cur`.  Unless it is the wave's last (LAST), the next block (kb_next)
+  // is requested meanwhile: its weights into `nxt` at the start, each half of its slab into the LDS half
+  // just consumed.  A wave's vector-memory operations, in issue order, are thus
+  //   W(0), D0(0), D1(0), W(1), D0(1), D1(1), W(2), ..          (D = XL DMA loads, W = WL loads)
+  // Half 0 of block i is read from the start of the block: all but the XL + WL youngest must be done
+  // (XL in the last block, which requests nothing).  Half 1 is first read during k-step 3 (fragments
+  // are fetched one k-step ahead), before D0(i+1) is issued: all but the WL youngest (none in the last
+  // block).  A half is overwritten only after the matrix instructions of its last k-step were issued,
+  // i.e. after its last read returned.  (Three half slabs per wave, the DMA a whole block ahead, were
+  // tried where LDS allows: no faster at 4 waves, and slower wherever the extra LDS costs a resident
+  // workgroup.)
+  auto block = [&](auto last_, int kb_next, const WSet& cur, WSet& nxt) {
+    constexpr bool LAST = decltype(last_)::value != 0;
+    SZ c[T];
+    f16x8 xa[MT], xb[MT];
+    if constexpr (!LAST) {
+      load_w(kb_next, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_vmcnt<LAST ? XL : XL + WL>();
+    read_x(0, xa);
+    f16x8 af0 = convert(0, 0, cur, c);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      // even k-step on xa while xb arrives, odd k-step on xb while xa arrives
+      read_x(k2 + 1, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2, cur, c, xa, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 + 1 == 3) wait_vmcnt<LAST ? 0 : WL>();
+      if (k2 + 2 < 8) read_x(k2 + 2, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2 + 1, cur, c, xb, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+        if (k2 + 1 == 3) dma_x(kb_next, 0);
+        if (k2 + 1 == 7) dma_x(kb_next, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef W4A16_STAMPS
+    STAMP(2 + min(n_done, 15));
+    ++n_done;
+#endif
+  };
+
+  // This wave's blocks.  With 8 waves the second wave of each SIMD gets its first requests out several
+  // thousand cycles after the first (the CU's memory path takes a workgroup's cold first round at a
+  // fraction of its steady rate) and would finish that much later; so the first four waves take a head
+  // start of two blocks each: blocks 0-7 go to waves 0-3 (w, w + 4), the rest round-robin over all eight
+  // (wave w: 8 + w, 16 + w, ..).  `next` steps through a wave's list.
+  // Blocks with a successor go two per trip (the weight sets swap roles, nothing in the loop body is
+  // conditional: a branch there makes the compiler's own wait counts collapse to "everything"); an odd
+  // one out hands its prefetched set over by register copy, so that the last block always reads `w0`
+  // and the accumulators never meet from two paths.
+  // With gridDim.y > 1 the workgroups of an output tile split K between them: this one takes the 128-k blocks
+  // [kb_lo, kb_hi) (the host leaves no split empty).
+  constexpr bool HEAD = (KW == 8);
+  const int kb_lo = blockIdx.y * sp.kb_per_split;
+  const int kb_hi = min(kb_lo + sp.kb_per_split, a.KB);
+  auto next = [&](int kb) { return (HEAD && kb - kb_lo < 8) ? kb + 4 : kb + KW; };
+  int kb = kb_lo + ((HEAD && w >= 4) ? 8 + w : w);
+  int nblk = 0;
+  for (int b = kb; b < kb_hi; b = next(b)) ++nblk;
+  if (nblk > 0) {
+    WSet w0, w1;
+    load_w(kb, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(26);
+    dma_x(kb, 0);
+    __builtin_amdgcn_sched_barrier(0);  // half 0 before half 1: the counted waits rely on the issue order
+    STAMP(27);
+    dma_x(kb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    int i = 0;
+    for (; i + 2 < nblk; i += 2) {
+      const int k1 = next(kb), k2 = next(k1);
+      block(Flag<0>{}, k1, w0, w1);
+      block(Flag<0>{}, k2, w1, w0);
+      kb = k2;
+    }
+    if (i + 1 < nblk) {
+      kb = next(kb);
+      block(Flag<0>{}, kb, w0, w1);
+      w0 = w1;
+    }
+    block(Flag<1>{}, kb, w0, w1);
+  }
+
+  // Cross-wave reduction through LDS (the slabs are free once every wave is past the first barrier).  A wave's
+  // partial result is T * MT * 4 slices of 1 KiB: 4 accumulator registers x 64 lanes, i.e. for tile (t, mt) and
+  // register group q the outputs of token 32 mt + r32, columns 32 t + 8 q + 4 h .. + 3.
+  //  * 8 waves: the upper four park their slices, the lower four add them to their accumulators and carry on alone.
+  //  * 4 waves: every slice has an OWNER wave that keeps its own share in registers; each wave leaves the slices it
+  //    does not own in their owners' inboxes (three quarters of the partial sums travel through LDS, once), then
+  //    adds the three inbox copies to each slice it owns, in wave order.  The owner of slice (tile, q) is wave q;
+  //    with the fused activation wave 2 (tile & 1) + (q & 1), so that the gate (q = 0, 1) and up (q = 2, 3) halves
+  //    of an output meet in one wave.
+  constexpr int TM = T * MT;
+  constexpr int NSL = TM * 4;
+  constexpr int PER = wide_slices_per_owner(MT, T, ACT);  // (with the fused activation and an odd tile count two owners hold a pair fewer)
+  static_assert(KW == 4 || KW == 8, "four partial sums meet in the final exchange");
+  static_assert(12 * PER * 1024 <= 160 * 1024, "inboxes: 4 owners x 3 senders x PER KiB");
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+  auto part = [&](int i) {
+    const int t = i / (MT * 4), mt = (i >> 2) % MT, q = i & 3;
+    return f32x4{acc[t][mt][4 * q], acc[t][mt][4 * q + 1], acc[t][mt][4 * q + 2], acc[t][mt][4 * q + 3]};
+  };
+  STAMP(20);
+  __syncthreads();
+  STAMP(21);
+  if constexpr (KW == 8) {
+    if (w >= 4) {
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) red[((w - 4) * NSL + i) * 64 + lane] = part(i);
+    }
+    __syncthreads();
+    if (w >= 4) return;  // (the barriers below count the waves that are still running)
+    {
+      // all reads first, then the sums: one round trip to LDS, not NSL of them
+      f32x4 other[NSL];
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) other[i] = red[(w * NSL + i) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < NSL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i / (MT * 4)][(i >> 2) % MT][4 * (i & 3) + e] += other[i][e];
+    }
+    __syncthreads();  // the parked slices have been read: their LDS is free for the inboxes
+  }
+  // compile-time in the unrolled loops below: owner of slice i and its position among the owner's slices
+  auto owner_of = [](int i) { return ACT ? 2 * ((i >> 2) & 1) + (i & 1) : (i & 3); };
+  auto pos_of = [](int i) { return ACT ? 2 * (i >> 3) + ((i >> 1) & 1) : (i >> 2); };
+  // fin[j]: the finished fp32 sums of the j-th slice this wave owns.  The accumulators can only be indexed with
+  // compile-time constants, so the body is instantiated once per wave number.
+  f32x4 fin[PER];
+  auto exchange = [&](auto me_) {
+    constexpr int ME = decltype(me_)::value;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int o = owner_of(i);
+      if (o != ME) red[((o * 3 + ((ME - o - 1) & 3)) * PER + pos_of(i)) * 64 + lane] = part(i);
+    }
+    __syncthreads();
+    STAMP(22);
+    // inbox f of owner ME holds the copy of wave (ME + 1 + f) & 3: summed in wave order 0, 1, 2, 3
+#pragma unroll
+    for (int j = 0; j < PER; ++j) fin[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) {
+        if (owner_of(i) != ME) continue;
+        const int j = pos_of(i);
+        if (src == ME)
+          fin[j] += part(i);
+        else
+          fin[j] += red[((ME * 3 + ((src - ME - 1) & 3)) * PER + j) * 64 + lane];
+      }
+    }
+  };
+  if (w == 0) exchange(Flag<0>{});
+  else if (w == 1) exchange(Flag<1>{});
+  else if (w == 2) exchange(Flag<2>{});
+  else exchange(Flag<3>{});
+
+  // K split over workgroups: every workgroup of an output tile leaves its finished partial sums in its own slot
+  // of the workspace (whole 1-KiB wave stores that go through to memory, each 128-byte line written by one
+  // instruction), waits for them to be acknowledged, and one lane draws a ticket.  The workgroup that draws the
+  // last ticket of the tile reads the other slots back (loads that bypass this CU's cache), adds all splits in
+  // split order, so the result does not depend on who came last, finishes the tile and returns the counter to
+  // zero for the next launch.
+  const int splits = gridDim.y;
+  if (splits > 1) {
+    const int tile = slice * m_blocks + mb;
+    const uint32_t slot = blockIdx.z * (n_slices * m_blocks) + tile;
+    constexpr uint32_t WGB = 4 * PER * 1024;  // bytes of one workgroup's partial sums
+    const __amdgpu_buffer_rsrc_t ws_rs = __builtin_amdgcn_make_buffer_rsrc(sp.ws, 0, sp.ws_bytes, 0x00020000);
+    const uint32_t lane_off = (uint32_t)(w * PER) * 1024u + lane * 16u;
+    constexpr int THROUGH = 16;  // cache policy sc1: the store goes through to memory, the load bypasses this CU's cache
+    const uint32_t mine = (slot * splits + blockIdx.y) * WGB;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fin[j]), ws_rs, lane_off + j * 1024, mine, THROUGH);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's stores are acknowledged before the ticket is drawn
+    unsigned* const flag = reinterpret_cast<unsigned*>(smem_raw + 12 * PER * 1024);  // (just above the inboxes)
+    if (threadIdx.x == 0)
+      *flag = __hip_atomic_fetch_add(&sp.tickets[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // the wave that drew the ticket has its answer before anybody loads
+    const unsigned old = __builtin_amdgcn_readfirstlane(*flag);
+    if (old != (unsigned)(splits - 1)) return;  // whole workgroup
+    for (int s2 = 0; s2 < splits; ++s2) {
+      const uint32_t theirs = (slot * splits + s2) * WGB;
+      f32x4 got[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        got[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws_rs, lane_off + j * 1024, theirs, THROUGH));
+#pragma unroll
+      for (int j = 0; j < PER; ++j) fin[j] = s2 == 0 ? got[j] : fin[j] + got[j];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&sp.tickets[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // Epilogue of the slices this wave owns: rounded to fp16 first, then the bias is added in fp16, then the
+  // activation: what the separate steps on an fp16 GEMM result give.
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if constexpr (ACT) {
+      // slices (tile, q) and (tile, q + 2): gate columns and the same columns of the up half
+      if (j & 1) continue;
+      const int tm = 2 * (j >> 1) + (w >> 1), q = w & 1;
+      if (tm >= TM) continue;
+      const int t = tm / MT, mt = tm % MT;
+      const int m = m0 + mt * 32 + r32;
+      const int NH = a.N / 2;
+      const int n = (ct0 + t) * 16 + 8 * q + 4 * h;
+      if (m < a.M && n < NH) {
+        const f32x4 v = fin[j], vu = fin[j + 1];
+        f16x4 hg = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        f16x4 hu = f16x4{(f16)vu.x, (f16)vu.y, (f16)vu.z, (f16)vu.w};
+        if (a.bias != nullptr) {
+          hg += *reinterpret_cast<const f16x4*>(a.bias + n);
+          hu += *reinterpret_cast<const f16x4*>(a.bias + NH + n);
+        }
+        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(hg, hu);
+      }
+    } else {
+      const int t = j / MT, mt = j % MT, q = w;
+      const int m = m0 + mt * 32 + r32;
+      const int n = (ct0 + t) * 32 + 8 * q + 4 * h;
+      if (m < a.M && n < a.N) {
+        const f32x4 v = fin[j];
+        f16x4 hv = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + n);
+        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
+        if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+        *dst = hv;
+      }
+    }
+  }
+  STAMP(23);
+#ifdef W4A16_STAMPS
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
+#endif
+}
+
+template <int MT, int T, int KW>
+int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
+  constexpr int stage = KW * MT * 32 * 256;  // one private slab per wave
+  constexpr int per = wide_slices_per_owner(MT, T, true);  // (the larger of the two epilogues' inbox sizes)
+  constexpr int inbox = 12 * per * 1024 + 16;               // 4 owners x 3 senders, then the ticket word
+  constexpr int park = KW > 4 ? 4 * T * MT * 4 * 1024 : 0;  // 8 waves: the upper four park whole partial tiles first
+  constexpr int reduce = park > inbox ? park : inbox;
+  constexpr int lds = stage > reduce ? stage : reduce;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  // whole 128-k blocks only, and 32-bit byte offsets into the three buffers
+  if (a.K % 128 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31)) return W4A16_E_SHAPE;
+  // fused activation: a tile is 16 gate + 16 up columns, so there are N / 32 of them too
+  if (act && a.N % 32) return W4A16_E_SHAPE;
+  const int n_slices = ceil_div(ceil_div(a.N, 32), T);
+  const int m_blocks = ceil_div(a.M, MT * 32);
+  const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
+  // K split over workgroups: 4-wave shapes only; every split gets at least one block per wave
+  if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
+  WideSplit sp{nullptr, nullptr, 0, a.KB};
+  if (splits > 1) {
+    if (KW != 4) return W4A16_E_SHAPE;
+    sp.kb_per_split = ceil_div(a.KB, splits);
+    splits = ceil_div(a.KB, sp.kb_per_split);  // no empty split
+  }
+  if (splits > 1) {
+    if (!ws) return W4A16_E_NULL;
+    if (misaligned(ws)) return W4A16_E_ALIGN;
+    const long long tiles = (long long)batch * n_slices * m_blocks;
+    const size_t need = wide_ws_bytes(tiles, splits, MT, T, act);
+    if (tiles > kMaxTickets || need - kTicketBytes >= (1ULL << 31)) return W4A16_E_SHAPE;
+    if (ws_bytes < need) return W4A16_E_WORKSPACE;
+    sp.tickets = static_cast<unsigned*>(ws);
+    sp.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + kTicketBytes);
+    sp.ws_bytes = (int)(need - kTicketBytes);
+  }
+  void (*kern)(int, int, int, const GemmArgs, const WideSplit) = nullptr;
+  if (act) {
+    if (a.G % 128 == 0)
+      kern = gemm_wide_kernel<MT, T, KW, 4, true>;
+    else if (a.G == 64)
+      kern = gemm_wide_kernel<MT, T, KW, 2, true>;
+    else
+      kern = gemm_wide_kernel<MT, T, KW, 1, true>;
+  } else if (a.G % 128 == 0)
+    kern = gemm_wide_kernel<MT, T, KW, 4>;
+  else if (a.G == 64)
+    kern = gemm_wide_kernel<MT, T, KW, 2>;
+  else
+    kern = gemm_wide_kernel<MT, T, KW, 1>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      w4a16_note_hip_error((int)e);
+      return W4A16_E_LAUNCH;
+    }
+  }
+  const int panel_rows = m_blocks > 8 ? kPanelRows : m_blocks;
+  GemmArgs am = a;
+  am.mb_magic = row_block_magic((long long)n_slices * m_blocks, m_blocks, panel_rows);
+  hipLaunchKernelGGL(kern, dim3(blocks, splits, batch), dim3(64 * KW), lds, s, n_slices, m_blocks, panel_rows, am, sp);
+  return launched();
+}
+
+}  // namespace
+
+int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch, bool act, int splits, void* ws,
+                  size_t ws_bytes) {
+#define X(MT_, T_, KW_) \
+  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch, act, splits, ws, ws_bytes);
+  W4A16_FOR_EACH_WIDE(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
+}  // namespace w4a16
+
+#if defined(W4A16_STAMPS) && !defined(W4A16_UNITY)
+// Diagnostic build of this translation unit alone (-DW4A16_STAMPS): copies its stamp buffer to host memory.
+extern "C" int w4a16_dbg_stamps(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w4a16::g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -1,0 +1,291 @@
+// libw4a16.so: the 32x32x16 GEMM kernel with one activation slab per workgroup (many rows) and its launcher.
+// Layout, arithmetic and the kernel families are described at the top of w4a16.hip.
+
+#include "w4a16_common.h"
+
+namespace W4A16_HIDDEN w4a16 {
+namespace {
+
+// ---------------------------------------------------------------------------
+// 32x32x16 GEMM for many rows: one activation slab shared by all waves of the workgroup
+// ---------------------------------------------------------------------------
+// With hundreds of rows and more the workgroup's traffic, not its arithmetic, decides: a [32 MT] x [32 T NW]
+// tile re-reads its activation rows once per workgroup, so the wider the tile the fewer bytes per
+// matrix instruction.  Here the NW waves of a workgroup each own T 32-column tiles for all MT 32-row
+// tiles over the WHOLE of K (no K split, so no cross-wave reduction: results go from the accumulators
+// straight to memory), and share the [32 MT rows] x [128 k] activation slab of the current block, which
+// the waves fetch together by LDS-DMA into a ring of three slabs (256-byte rows, 16-byte chunks
+// XOR-swizzled by the row), two blocks ahead.  A weight fragment converted once feeds MT matrix
+// instructions: with MT = 4 the conversion takes a quarter of the vector issue slots of the 16x16x32
+// kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
+// landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
+
+template <int MT, int T, int NW, int SZS, bool ACT = false>
+__global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1)) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
+                                                                   const GemmArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+  fetch_args_now(ga);
+  asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
+  if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
+  const GemmArgs a = batch_slice(ga);
+  constexpr int R = MT * 32;
+  constexpr int SLAB = R * 256;             // bytes: R rows x 128 k
+  constexpr int PIECES = R / 4;             // DMA instructions per slab (4 rows x 256 bytes each)
+  static_assert(PIECES % NW == 0, "every wave fetches the same number of pieces");
+  constexpr int ND = PIECES / NW;           // ... per wave
+  constexpr int NSZ = 4 / SZS;
+  constexpr int WL = T * (NSZ + 2);         // register loads per weight block and wave
+  constexpr int RING = ring_slabs<MT, T, NW>();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  int slice, mb;
+  if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
+  // fused activation: a tile is 16 gate columns and the same 16 columns of the up half (as in gemm_wide_kernel)
+  const int ct0 = (slice * NW + w) * T;  // this wave's first tile
+  const int m0 = mb * R;
+  auto tile16 = [&](int t) {
+    const int second = (lane >> 4) & 1;
+    if constexpr (ACT) {
+      const int nth = a.NT / 2;
+      return min(ct0 + t, nth - 1) + second * nth;
+    }
+    return min(2 * (ct0 + t) + second, a.NT - 1);
+  };
+
+  uint32_t woff[T], szoff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int t16 = tile16(t);
+    woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
+    szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
+  }
+  // this wave's pieces of a slab: piece p = w + NW j covers rows 4 p .. 4 p + 3; lane -> row 4 p + (lane >> 4),
+  // 16-byte position lane & 15, which holds chunk (lane & 15) ^ (row & 15) of the row's 128 k
+  uint32_t xoff[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int row = 4 * (w + NW * j) + (lane >> 4);
+    xoff[j] = ((uint32_t)min(m0 + row, a.M - 1) * a.K + ((lane & 15) ^ (row & 15)) * 8) * 2u;
+  }
+  // B fragment of k-step ks (0..7): row r32 (+ 32 mt), chunk 2 ks + h
+  const int xrd = r32 * 256;
+  const int xsw = r32 & 15;
+
+  f32x16 acc[T][MT];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  const DqConst dqc = make_dq_const();
+
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  struct WSet {
+    uint32_t sz[T][NSZ];
+    u32x4 q[T][2];
+  };
+  auto load_w = [&](int kb, WSet& b) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) {
+        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
+        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
+      b.q[t][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + 512, kb * 1024, 0);
+    }
+  };
+  auto dma_x = [&](int kb, int buf) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w + NW * j) * 1024), 16, xoff[j],
+          kb * 256, 0, 0);
+  };
+  auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
+  };
+  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+  };
+  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
+    f16x8 af[T + 1];
+    af[0] = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T)
+        af[t + 1] = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        af[T] = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+    }
+    if (kstep + 1 < 8) af0 = af[T];
+    constexpr int per = (13 + MT - 1) / MT;
+#pragma unroll
+    for (int i = 0; i < T * MT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+    }
+  };
+  // Block i from weight set `cur` in ring slab i % 3.  A wave's vector-memory operations, in issue order:
+  //   D(0), D(1), W(0) | D(2), W(1) | D(3), W(2) | ..      (D = its ND DMA loads of a slab, W = WL loads)
+  // one group per block, issued right after the block's barrier.  Before the barrier of block i the wave's
+  // own share of D(i) must have landed: all but the ND + WL youngest (D(i+1), W(i)) are done then; in the
+  // last block D(i+1) does not exist: all but the WL youngest.
+  // DMA 0/1: whether D(i+2) exists; LW: whether W(i+1) exists.
+  auto block = [&](auto dma, auto lw, int i, const WSet& cur, WSet& nxt) {
+    constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
+    const int base = (i % RING) * SLAB + xrd;
+    // (two slabs: D(i+1) is issued after this barrier, so only W(i) is younger than D(i))
+    wait_vmcnt<(LW && RING == 3) ? ND + WL : WL>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DMA) dma_x(i + RING - 1, (i + RING - 1) % RING);
+    __builtin_amdgcn_sched_barrier(0);  // the wait counts above rely on this issue order: DMA first, then weights
+    if constexpr (LW) load_w(i + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    SZ c[T];
+    f16x8 xa[MT], xb[MT];
+    read_x(0, base, xa);
+    f16x8 af0 = convert(0, 0, cur, c);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      read_x(k2 + 1, base, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2, cur, c, xa, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 + 2 < 8) read_x(k2 + 2, base, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      math(k2 + 1, cur, c, xb, af0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int n = a.KB;  // >= 2 (host-checked)
+  WSet w0, w1;
+  dma_x(0, 0);
+  if constexpr (RING == 3) dma_x(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(0, w0);
+  __builtin_amdgcn_sched_barrier(0);
+  int i = 0;
+  for (; i + 2 <= n - 2; i += 2) {
+    block(Flag<1>{}, Flag<1>{}, i, w0, w1);
+    block(Flag<1>{}, Flag<1>{}, i + 1, w1, w0);
+  }
+  if (i < n - 2) {
+    block(Flag<1>{}, Flag<1>{}, i, w0, w1);
+    w0 = w1;
+    ++i;
+  }
+  block(Flag<RING == 2>{}, Flag<1>{}, i, w0, w1);  // (two slabs: the last block's slab is still to be fetched)
+  block(Flag<0>{}, Flag<0>{}, i + 1, w1, w0);
+
+  // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + mt * 32 + r32;
+        if constexpr (ACT) {
+          // register groups 0, 1 are gate columns, 2, 3 the same columns of the up half; rounded to fp16,
+          // bias added in fp16, then the activation, as the separate steps would
+          const int NH = a.N / 2;
+          const int nn = (ct0 + t) * 16 + 8 * q + 4 * h;
+          if (q < 2 && m < a.M && nn < NH) {
+            constexpr int up = ACT ? 8 : 0;
+            f16x4 hg = f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2],
+                             (f16)acc[t][mt][4 * q + 3]};
+            f16x4 hu = f16x4{(f16)acc[t][mt][(4 * q + up) & 15], (f16)acc[t][mt][(4 * q + 1 + up) & 15],
+                             (f16)acc[t][mt][(4 * q + 2 + up) & 15], (f16)acc[t][mt][(4 * q + 3 + up) & 15]};
+            if (a.bias != nullptr) {
+              hg += *reinterpret_cast<const f16x4*>(a.bias + nn);
+              hu += *reinterpret_cast<const f16x4*>(a.bias + NH + nn);
+            }
+            *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + nn) = silu_mul(hg, hu);
+          }
+        } else if (const int nn = (ct0 + t) * 32 + 8 * q + 4 * h; m < a.M && nn < a.N) {
+          f16x4 hv = f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2],
+                           (f16)acc[t][mt][4 * q + 3]};
+          if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + nn);
+          f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + nn);
+          if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+          *dst = hv;
+        }
+      }
+#endif
+}
+
+template <int MT, int T, int NW>
+int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
+  constexpr int lds = ring_slabs<MT, T, NW>() * MT * 32 * 256;  // ring of slabs
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  // whole 128-k blocks, at least two of them, and 32-bit byte offsets into the three buffers
+  if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
+    return W4A16_E_SHAPE;
+  if (act && a.N % 32) return W4A16_E_SHAPE;
+  const int n_slices = ceil_div(ceil_div(a.N, 32), T * NW);
+  const int m_blocks = ceil_div(a.M, MT * 32);
+  const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
+  void (*kern)(int, int, int, const GemmArgs) = nullptr;
+  if (act) {
+    if (a.G % 128 == 0)
+      kern = gemm_wide_shared_kernel<MT, T, NW, 4, true>;
+    else if (a.G == 64)
+      kern = gemm_wide_shared_kernel<MT, T, NW, 2, true>;
+    else
+      kern = gemm_wide_shared_kernel<MT, T, NW, 1, true>;
+  } else if (a.G % 128 == 0)
+    kern = gemm_wide_shared_kernel<MT, T, NW, 4>;
+  else if (a.G == 64)
+    kern = gemm_wide_shared_kernel<MT, T, NW, 2>;
+  else
+    kern = gemm_wide_shared_kernel<MT, T, NW, 1>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      w4a16_note_hip_error((int)e);
+      return W4A16_E_LAUNCH;
+    }
+  }
+  const int panel_rows = m_blocks > 8 ? kPanelRows : m_blocks;
+  GemmArgs am = a;
+  am.mb_magic = row_block_magic((long long)n_slices * m_blocks, m_blocks, panel_rows);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1, batch), dim3(64 * NW), lds, s, n_slices, m_blocks, panel_rows, am);
+  return launched();
+}
+
+
+}  // namespace
+
+int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch, bool act) {
+#define X(MT_, T_, NW_) \
+  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch, act);
+  W4A16_FOR_EACH_WIDE_SHARED(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
+
+
+}  // namespace w4a16
