@@ -149,6 +149,23 @@ def load_traffic():
     return {}
 
 
+def load_mfma():
+    """Matrix-core utilisation per kernel from the committed counter profile (its own rocprofv3 --pmc pass:
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)), if any; stamped with kernel names like the traffic."""
+    path = os.path.join(ROOT, "profiles", "mfma.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+def mfma_busy_of(mfma, m, kernel):
+    """The counter figure measured at `m` rows, if the profile was taken on `kernel`."""
+    if mfma.get(f"m{m}_kernel") != kernel:
+        return None
+    return mfma.get(f"m{m}_mfma_busy")
+
+
 def traffic_of(traffic, key, kernel):
     """The measured HBM bytes per launch under `key`, if the profile was taken on `kernel`."""
     if traffic.get(f"{key}_kernel") != kernel:
@@ -449,6 +466,7 @@ def main():
     # roofline of the dominant kernel of the timed region: the M=128 GEMM on this rank's column shard
     # (at N=1 the whole layer).  Algorithmic flops per launch / mean launch duration.
     traffic = load_traffic()
+    mfma = load_mfma()
     n_local = N // p
     flops_launch = 2.0 * M * K * n_local
     from vllm_quick_amd._lib import launch_shape
@@ -463,6 +481,10 @@ def main():
         "frac": flops_launch / col_us * 1e-6 / PEAK_F16_TFLOPS,
         "traffic": traffic_of(traffic, "m128", kernel) if p == 1 else None,
         "traffic_source": traffic.get("source") if p == 1 else None,
+        # counter-based: share of the matrix pipes' cycles in use while their CU is busy (see profiles/README.md);
+        # `frac` above divides by the 2.4 GHz data-sheet peak, the counters tick with the clock the chip holds
+        "mfma_busy": mfma_busy_of(mfma, M, kernel) if p == 1 else None,
+        "mfma_busy_source": mfma.get("source") if p == 1 else None,
         "algorithmic_bytes": algorithmic_bytes(M, K, n_local, G),
         "launch_us": col_us,
     }
@@ -481,7 +503,8 @@ def main():
                 by, fl = algorithmic_bytes(m, K, N, G), 2.0 * m * K * N
                 sweep[str(m)] = {"kernel": launch_shape(m, K, N), "us": us, "GBps": by / us * 1e-3,
                                  "TFLOPs": fl / us * 1e-6, "hbm_frac": by / us * 1e-3 / PEAK_HBM_GBPS,
-                                 "mfma_frac": fl / us * 1e-6 / PEAK_F16_TFLOPS}
+                                 "mfma_frac": fl / us * 1e-6 / PEAK_F16_TFLOPS,
+                                 "mfma_busy": mfma_busy_of(mfma, m, launch_shape(m, K, N))}
                 if m in (1, 16, 128):
                     sweep[str(m)]["stock_layout_kernel_us"] = time_launches(
                         [(lambda w=w: ops.awq_gemm_stock(xm, *w)) for w in stock], stream, 32, 8)

@@ -3,7 +3,9 @@
 usage: python scripts/summarize_profile.py r1
 Writes profiles/<tag>_kernel_stats.csv (per-kernel durations of the `--kernel-trace --stats` run),
 profiles/<tag>_traffic.json and profiles/traffic.json (HBM bytes per launch of the GEMM kernels,
-from the separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes).
+from the separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes) and, where a `<tag>_pmc_mfma` pass
+exists, profiles/<tag>_mfma.json and profiles/mfma.json (matrix-core utilisation per GEMM kernel from
+SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CU_CYCLES).
 
 Counter conventions (MI355X): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a
 wide coalesced streaming read (16 B per lane, which is what these kernels issue) at exactly half
@@ -108,6 +110,39 @@ traffic["source"] = f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / 
 for name in (f"{tag}_traffic.json", "traffic.json"):
     with open(os.path.join(out_dir, name), "w") as f:
         json.dump(traffic, f, indent=1)
+# ---- matrix-core utilisation from counters (its own --pmc pass) ----
+# SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is busy, summed over all SIMDs (32 per v_mfma_f32_32x32x16_f16,
+# 16 per 16x16x32).  SQ_BUSY_CU_CYCLES: cycles a CU holds at least one wave, summed over all CUs.  A CU has 4 SIMDs:
+#   mfma_busy = MFMA_BUSY / (4 * BUSY_CU)     share of the matrix pipes' time in use while their CU is busy
+# The counters tick with the clock the chip actually holds (it drops to ~1.6-2.0 GHz under matrix load), so this
+# figure is higher than flops / time / (the 2.5 PFLOP/s the data sheet quotes at 2.4 GHz) by that clock ratio and by
+# the share of CUs a launch leaves idle.
+mfma_files = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_mfma/**/*counter_collection.csv"), recursive=True)
+if mfma_files:
+    busy = per_kernel(mfma_files[0], "SQ_VALU_MFMA_BUSY_CYCLES")
+    cu = per_kernel(mfma_files[0], "SQ_BUSY_CU_CYCLES")
+    mfma = {"_note": "per launch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): share of the "
+                     "matrix pipes' time in use while their CU holds a wave (own --pmc pass)",
+            "kernels": {}}
+    for k in sorted(busy):
+        if k not in cu or cu[k][0] <= 0:
+            continue
+        mfma["kernels"][k] = {"launches": busy[k][1], "SQ_VALU_MFMA_BUSY_CYCLES": busy[k][0],
+                              "SQ_BUSY_CU_CYCLES": cu[k][0], "mfma_busy": busy[k][0] / (4.0 * cu[k][0])}
+    for m in (32, 128, 512, 1024, 4096):
+        want = launch_shape(m, 4096, 11008)
+        for k, v in mfma["kernels"].items():
+            if k.replace(" ", "").startswith(want[:-1] + ","):
+                mfma[f"m{m}_kernel"] = want
+                mfma[f"m{m}_mfma_busy"] = v["mfma_busy"]
+                mfma[f"m{m}_mfma_busy_cycles"] = v["SQ_VALU_MFMA_BUSY_CYCLES"]
+    mfma["commit"], mfma["dirty"] = traffic["commit"], traffic["dirty"]
+    mfma["source"] = (f"profiles/{tag}_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES on "
+                      "bench.py --sweep-ms 32,128,512,1024,4096)")
+    for name in (f"{tag}_mfma.json", "mfma.json"):
+        with open(os.path.join(out_dir, name), "w") as f:
+            json.dump(mfma, f, indent=1)
+    print(json.dumps(mfma, indent=1))
 for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json")):
     if os.path.exists(os.path.join(ROOT, "gpurun_out", src)):
         shutil.copyfile(os.path.join(ROOT, "gpurun_out", src), os.path.join(out_dir, dst))

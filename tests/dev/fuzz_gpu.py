@@ -1,150 +1,20 @@
-"""Randomised parity sweep on a GPU box: random shapes, group sizes, row counts and entry points
-(default launch shapes) against the oracle.  Developer check; prints a line per failure.
+"""Randomised parity sweep on a GPU box: random shapes, group sizes, row counts and entry points (default and
+forced launch shapes) against the oracle.  Developer check with a time budget; a fixed slice of the same cases is
+collected by pytest (tests/test_fuzz_gpu.py).  Prints a line per failure.
 
 usage: python tests/dev/fuzz_gpu.py [seconds] [seed] [large]
 """
-import os, sys, time
-import numpy as np
-import torch
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import awq_oracle as orc
-from vllm_quick_amd._C import ops
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _fuzz import sweep  # noqa: E402
 
-dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
-RT, AT = 1e-2, 1e-3
-
-
-STREAM = [(1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 1, 8), (1, 2, 8), (1, 3, 8), (1, 4, 8), (1, 6, 8), (1, 8, 8), (1, 1, 4),
-          (1, 2, 4), (1, 3, 4), (1, 4, 4), (2, 1, 16), (2, 1, 8), (2, 2, 8), (2, 3, 8), (2, 4, 8), (2, 6, 8), (2, 1, 4),
-          (2, 2, 4), (2, 3, 4), (4, 1, 8), (4, 2, 8), (4, 3, 8), (4, 4, 8), (4, 6, 8), (4, 1, 4), (4, 2, 4), (4, 3, 4),
-          (8, 1, 8), (8, 2, 8), (8, 3, 8), (8, 1, 4), (8, 2, 4), (8, 3, 4)]
-TILED = [(4, 2, 3, 4), (4, 3, 2, 4), (4, 3, 1, 4), (4, 2, 2, 4), (4, 3, 2, 2), (4, 3, 4, 2), (2, 3, 2, 4), (2, 3, 1, 4),
-         (8, 3, 1, 2), (8, 3, 2, 2), (4, 6, 1, 4), (2, 6, 1, 4), (1, 3, 1, 8), (1, 1, 3, 4), (1, 3, 1, 4), (2, 3, 1, 8)]
-ACT = [(1, 2, 16, 0), (1, 2, 8, 0), (1, 4, 8, 0), (1, 6, 8, 0), (1, 8, 8, 0), (1, 2, 4, 0), (1, 4, 4, 0), (2, 2, 8, 0),
-       (2, 4, 8, 0), (2, 6, 8, 0), (2, 2, 4, 0), (4, 3, 2, 4), (4, 3, 2, 2), (4, 3, 4, 2), (2, 3, 2, 4)]
-
-
-def t(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
-
-def close(got, want, exact, what):
-    """The policy of tests/test_gemm_gpu.py (assert_parity): within rtol/atol of the reference-faithful
-    result, except for a few outputs where that result's own fp16 slice rounding (it grows with K and
-    |y|) exceeds the bound; those must be within the bound of the fp64 result, and overall the kernel
-    must be no further from fp64 than the reference arithmetic is."""
-    got = got.astype(np.float64)
-    bad = np.abs(got - want) > AT + RT * np.abs(want)
-    if bad.sum() == 0:
-        return True
-    ok = bad.sum() <= max(2, 1e-3 * bad.size) and (np.abs(got - exact)[bad] <= AT + RT * np.abs(exact[bad])).all() \
-        and np.abs(got - exact).max() <= np.abs(want - exact).max() * 1.05 + 2.0**-11 * max(1.0, np.abs(exact).max())
-    if not ok:
-        print(f"FAIL {what}: {bad.sum()} of {bad.size} outside tolerance, max|d| {np.abs(got - want).max():.3e}, "
-              f"vs fp64 {np.abs(got - exact).max():.3e} (reference arithmetic {np.abs(want - exact).max():.3e})", flush=True)
-    return ok
-
-
-t0, n, fails = time.time(), 0, 0
-while time.time() - t0 < budget:
-    G = int(rng.choice([32, 64, 128, 256]))
-    K = G * int(rng.integers(1, 24))
-    N = 8 * int(rng.integers(1, 120))
-    if LARGE:  # model-sized layers (fewer cases: the CPU oracle takes seconds on these)
-        G = 128
-        K, N = [(4096, 1376), (4096, 2752), (11008, 4096), (4096, 4096), (2048, 11008), (4096, 5504)][rng.integers(6)]
-    M = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 200, 300]))
-    mode = rng.choice(["gemm", "stock", "dequant", "batched", "act", "act_batched", "cfg", "cfg", "act_cfg", "decode", "decode"])
-    if mode == "decode":  # the decode kernel with a forced shape: up to 16 rows, whole 128-k blocks
-        M = int(rng.integers(1, 17))
-        K = 128 * int(rng.integers(1, 40)) if G <= 128 else G * int(rng.integers(1, 20))
-        N = 16 * int(rng.integers(1, 60))
-    x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
-    what = f"{mode} M={M} K={K} N={N} G={G}"
-    try:
-        if mode == "dequant":
-            w = orc.dequantize(qw, s, qz)
-            a = ops.awq_dequantize(t(qw), t(s), t(qz), 0, 0, 0).cpu().numpy()
-            b = ops.awq_dequantize_packed(ops.awq_repack(t(qw), t(s), t(qz))).cpu().numpy()
-            ok = (a.view(np.uint16) == w.view(np.uint16)).all() and (b.view(np.uint16) == w.view(np.uint16)).all()
-            if not ok:
-                print(f"FAIL {what}: dequantise not bit-exact", flush=True)
-        elif mode in ("gemm", "stock"):
-            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
-            fn = ops.awq_gemm if mode == "gemm" else (lambda a, b, c, d, _: ops.awq_gemm_stock(a, b, c, d))
-            ok = close(fn(t(x), t(qw), t(s), t(qz), 8).float().cpu().numpy(), want, exact, what)
-        elif mode == "cfg":
-            # a forced launch shape out of the built tables (row tiles must cover M for the streaming kernel)
-            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
-            cfg = STREAM[rng.integers(len(STREAM))] if rng.integers(2) else TILED[rng.integers(len(TILED))]
-            what += f" cfg={cfg}"
-            pk = ops.awq_repack(t(qw), t(s), t(qz))
-            try:
-                y = ops.awq_gemm_packed(t(x), pk, cfg=cfg)
-            except ValueError:
-                continue  # shape/launch combination the library refuses (e.g. K blocks not divisible by kw)
-            ok = close(y.float().cpu().numpy(), want, exact, what)
-        elif mode == "decode":
-            from vllm_quick_amd import _lib
-            want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
-            shapes = _lib.built_shapes(4)
-            tt, ww, _ = shapes[rng.integers(len(shapes))]
-            splits = int(rng.integers(1, 5)) if M <= 4 and tt <= 4 else 1
-            cfg = ("decode", int(tt), int(ww), splits, int(rng.integers(0, 3)))
-            what += f" cfg={cfg}"
-            pk = ops.awq_repack(t(qw), t(s), t(qz))
-            y = ops.awq_gemm_packed(t(x), pk, cfg=cfg, workspace=ops.gemm_workspace(dev) if splits > 1 else None)
-            ok = close(y.float().cpu().numpy(), want, exact, what)
-        elif mode == "batched":
-            E = int(rng.integers(2, 5))
-            ws = [orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30))) for _ in range(E)]
-            shared = bool(rng.integers(2)) or (M * K) % 8 != 0
-            if (M * N) % 4:
-                continue
-            pk = ops.awq_repack_batch([t(w[1]) for w in ws], [t(w[2]) for w in ws], [t(w[3]) for w in ws])
-            xs = ws[0][0] if shared else np.stack([w[0] for w in ws])
-            y = ops.awq_gemm_packed_batched(t(xs), pk).float().cpu().numpy()
-            ok = all(close(y[e], orc.gemm_faithful(xs if shared else xs[e], *ws[e][1:]).astype(np.float64),
-                           orc.gemm_exact(xs if shared else xs[e], *ws[e][1:]), what + f" e={e}") for e in range(E))
-        else:
-            N = 32 * max(1, N // 32)
-            x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
-            what = f"{mode} M={M} K={K} N={N} G={G}"
-            y = orc.gemm_faithful(x, qw, s, qz)
-            g, u = torch.from_numpy(y[:, :N // 2]), torch.from_numpy(y[:, N // 2:])
-            want = (torch.nn.functional.silu(g.float()).half() * u).numpy().astype(np.float64)
-            gd, ud = g.numpy().astype(np.float64), u.numpy().astype(np.float64)
-            sg = gd / (1 + np.exp(-gd))
-            tol = 1.1 * np.abs(ud) * (AT + RT * np.abs(gd)) + np.abs(sg) * (AT + RT * np.abs(ud)) + 2.0**-10 * np.abs(sg * ud) + 1e-6
-            pk = ops.awq_repack(t(qw), t(s), t(qz))
-            if mode == "act":
-                got = ops.awq_gemm_packed_silu_and_mul(t(x), pk).float().cpu().numpy()
-            elif mode == "act_cfg":
-                cfg = ACT[rng.integers(len(ACT))]
-                what += f" cfg={cfg}"
-                try:
-                    got = ops.awq_gemm_packed_silu_and_mul(t(x), pk, cfg=cfg).float().cpu().numpy()
-                except ValueError:
-                    continue
-            else:
-                if (M * (N // 2)) % 4:
-                    continue
-                pkb = ops.awq_repack_batch([t(qw)] * 2, [t(s)] * 2, [t(qz)] * 2)
-                got = ops.awq_gemm_packed_silu_and_mul(t(x), pkb).float().cpu().numpy()[1]
-            err = np.abs(got - want)
-            ok = bool((err > tol).sum() <= max(2, 1e-4 * err.size) and (err <= 4 * tol).all())
-            if not ok:
-                print(f"FAIL {what}: {(err > tol).sum()} outside tolerance", flush=True)
-    except Exception as e:  # noqa: BLE001
-        ok = False
-        print(f"ERROR {what}: {type(e).__name__}: {e}", flush=True)
-    n += 1
-    fails += not ok
-    if n % (5 if LARGE else 50) == 0:
-        print(f"[fuzz] {n} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"[fuzz] done: {n} cases, {fails} failures")
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+large = len(sys.argv) > 3 and sys.argv[3] == "large"
+n, fails = sweep(seed, budget_s=budget, large=large, verbose=True)
+print(f"[fuzz] done: {n} cases, {len(fails)} failures")
 sys.exit(1 if fails else 0)
