@@ -223,6 +223,28 @@ struct DecodeArgs {
   int gx;             // workgroup columns (gridDim.x)
 };
 
+// Checking build of the 32x32x16 kernels (-DW4A16_CHECK_DMA, libw4a16_check.so; never the shipped library).  Their
+// activation slabs arrive by LDS-DMA, whose completion the kernels await with hand-counted `s_waitcnt vmcnt(n)`: a
+// miscount (an edit to the issue order, a compiler that reorders two loads) shows as a rare wrong tile.  Here every
+// piece of LDS is filled with a poison pattern right before the DMA into it is issued, and every fragment read back
+// is checked for the pattern: a read that overtakes its DMA is counted, every time.  g_dma_state[1] != 0 is the
+// negative control of the test: the kernels then skip the counted waits AND read one piece back right behind the
+// DMA instruction that fills it (the waits have slack whenever a slab arrives early, so skipping them alone need
+// not show; a read a few cycles behind the DMA's issue cannot see its data).
+#ifdef W4A16_CHECK_DMA
+constexpr uint32_t kDmaPoison = 0xffffffffu;  // two fp16 NaNs no finite activation pair equals
+#define W4A16_DMA_STATE_DECL static __device__ unsigned g_dma_state[2];
+__device__ __forceinline__ void dma_check(const u32x4 v, unsigned* state) {
+  if (v.x == kDmaPoison || v.y == kDmaPoison || v.z == kDmaPoison || v.w == kDmaPoison) atomicAdd(state, 1u);
+}
+#define W4A16_DMA_WAIT(N)                                   \
+  do {                                                      \
+    if (!dma_skip_waits) wait_vmcnt<(N)>();                 \
+  } while (0)
+#else
+#define W4A16_DMA_WAIT(N) wait_vmcnt<(N)>()
+#endif
+
 // K split over workgroups of the private-slab 32x32x16 kernel (gridDim.y splits; one split: all null / whole K).
 struct WideSplit {
   float* ws;          // partial sums: [output tile][split][wave][slice][64 lanes] x 16 bytes

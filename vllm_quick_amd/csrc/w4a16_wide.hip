@@ -3,6 +3,12 @@
 
 #include "w4a16_common.h"
 
+#ifdef W4A16_CHECK_DMA
+namespace W4A16_HIDDEN w4a16 {
+W4A16_DMA_STATE_DECL
+}
+#endif
+
 namespace W4A16_HIDDEN w4a16 {
 namespace {
 
@@ -47,6 +53,9 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, h = lane >> 5;
+#ifdef W4A16_CHECK_DMA
+  const bool dma_skip_waits = __builtin_amdgcn_readfirstlane(g_dma_state[1]) != 0;
+#endif
 #ifdef W4A16_STAMPS
   constexpr int NWAVES = KW;
   int n_done = 0;
@@ -143,11 +152,20 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
   // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
   auto dma_x = [&](int kb, int hp) {
+#ifdef W4A16_CHECK_DMA
+#pragma unroll
+    for (int p = 0; p < XLR; ++p)
+      *reinterpret_cast<u32x4*>(smem_raw + wbase + hp * HALF + p * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pattern is in place before the DMA can land on it
+#endif
 #pragma unroll
     for (int p = 0; p < XL; ++p)  // (ablation 1: XL is 1, an eighth of the activation traffic)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           x_rs, (__attribute__((address_space(3))) void*)(smem_raw + wbase + hp * HALF + p * 1024), 16, xoff[p],
           (kb * 128 + hp * 64) * 2, 0, 0);
+#ifdef W4A16_CHECK_DMA
+    if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + wbase + hp * HALF + lane * 16), &g_dma_state[0]);
+#endif
   };
   // B fragments of k-step `kstep` (0..7) of the block: 2 ds_read_b128 from half kstep / 4
   auto read_x = [&](int kstep, f16x8 (&xf)[MT]) {
@@ -155,6 +173,11 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + hp * HALF + mt * 4096);
+#ifdef W4A16_CHECK_DMA
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      dma_check(__builtin_bit_cast(u32x4, xf[mt]), &g_dma_state[0]);
+#endif
   };
   // The weight fragment of tile t at k-step `kstep` (scale/zero constants refreshed where a new group starts)
   auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
@@ -209,7 +232,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       load_w(kb_next, nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
-    wait_vmcnt<LAST ? XL : XL + WL>();
+    W4A16_DMA_WAIT(LAST ? XL : XL + WL);
     read_x(0, xa);
     f16x8 af0 = convert(0, 0, cur, c);
 #pragma unroll
@@ -219,7 +242,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       __builtin_amdgcn_sched_barrier(0);
       math(k2, cur, c, xa, af0);
       __builtin_amdgcn_sched_barrier(0);
-      if (k2 + 1 == 3) wait_vmcnt<LAST ? 0 : WL>();
+      if (k2 + 1 == 3) W4A16_DMA_WAIT(LAST ? 0 : WL);
       if (k2 + 2 < 8) read_x(k2 + 2, xa);
       __builtin_amdgcn_sched_barrier(0);
       math(k2 + 1, cur, c, xb, af0);
@@ -520,5 +543,18 @@ int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int b
 // Diagnostic build of this translation unit alone (-DW4A16_STAMPS): copies its stamp buffer to host memory.
 extern "C" int w4a16_dbg_stamps(void* host_out, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w4a16::g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+#ifdef W4A16_CHECK_DMA
+// Checking build: reads {fragments that overtook their DMA, skip-waits switch}; `set_skip` >= 0 writes the switch and
+// clears the count (synchronises).
+extern "C" int w4a16_dbg_dma_state_wide(unsigned* host_state, int set_skip) {
+  if (set_skip >= 0) {
+    const unsigned v[2] = {0u, (unsigned)set_skip};
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(w4a16::g_dma_state), v, sizeof(v), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipMemcpyFromSymbol(host_state, HIP_SYMBOL(w4a16::g_dma_state), 2 * sizeof(unsigned), 0, hipMemcpyDeviceToHost);
 }
 #endif

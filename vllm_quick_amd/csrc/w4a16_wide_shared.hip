@@ -3,6 +3,12 @@
 
 #include "w4a16_common.h"
 
+#ifdef W4A16_CHECK_DMA
+namespace W4A16_HIDDEN w4a16 {
+W4A16_DMA_STATE_DECL
+}
+#endif
+
 namespace W4A16_HIDDEN w4a16 {
 namespace {
 
@@ -41,6 +47,9 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r32 = lane & 31, h = lane >> 5;
+#ifdef W4A16_CHECK_DMA
+  const bool dma_skip_waits = __builtin_amdgcn_readfirstlane(g_dma_state[1]) != 0;
+#endif
 
   int slice, mb;
   if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
@@ -109,16 +118,30 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     }
   };
   auto dma_x = [&](int kb, int buf) {
+#ifdef W4A16_CHECK_DMA
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      *reinterpret_cast<u32x4*>(smem_raw + buf * SLAB + (w + NW * j) * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pattern is in place before the DMA can land on it
+#endif
 #pragma unroll
     for (int j = 0; j < ND; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w + NW * j) * 1024), 16, xoff[j],
           kb * 256, 0, 0);
+#ifdef W4A16_CHECK_DMA
+    if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + buf * SLAB + w * 1024 + lane * 16), &g_dma_state[0]);
+#endif
   };
   auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
+#ifdef W4A16_CHECK_DMA
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      dma_check(__builtin_bit_cast(u32x4, xf[mt]), &g_dma_state[0]);
+#endif
   };
   auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
     if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
@@ -155,7 +178,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
     const int base = (i % RING) * SLAB + xrd;
     // (two slabs: D(i+1) is issued after this barrier, so only W(i) is younger than D(i))
-    wait_vmcnt<(LW && RING == 3) ? ND + WL : WL>();
+    W4A16_DMA_WAIT((LW && RING == 3) ? ND + WL : WL);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DMA) dma_x(i + RING - 1, (i + RING - 1) % RING);
@@ -289,3 +312,16 @@ int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s
 
 
 }  // namespace w4a16
+
+#ifdef W4A16_CHECK_DMA
+// Checking build: reads {fragments that overtook their DMA, skip-waits switch}; `set_skip` >= 0 writes the switch and
+// clears the count (synchronises).
+extern "C" int w4a16_dbg_dma_state_shared(unsigned* host_state, int set_skip) {
+  if (set_skip >= 0) {
+    const unsigned v[2] = {0u, (unsigned)set_skip};
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(w4a16::g_dma_state), v, sizeof(v), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipMemcpyFromSymbol(host_state, HIP_SYMBOL(w4a16::g_dma_state), 2 * sizeof(unsigned), 0, hipMemcpyDeviceToHost);
+}
+#endif
