@@ -134,3 +134,50 @@ def test_python_binding_counts_and_warns_when_the_stock_kernel_serves(ops, cuda)
         assert any("stock-layout kernel" in str(w.message) for w in seen)
     want = orc.gemm_faithful(*[t.cpu().numpy() for t in (x2, qw2, s2, qz2)])
     assert np.allclose(y2.float().cpu().numpy(), want.astype(np.float32), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("binding", ["native", "ctypes"])
+def test_weights_without_version_counters_are_never_served_stale(native, ops, cuda, binding):
+    """Tensors created under torch.inference_mode() keep no version counter, so an in-place reload of them cannot be
+    told from no change: neither binding keeps a packed copy for them (every call re-packs, said once).  Writes
+    through `param.data` (the reference's loaders) do not touch the counter of a normal tensor either: there the
+    caller clears the cache after the load, as the integration notes require."""
+    import warnings
+    gemm = native.ops.awq_gemm if binding == "native" else ops.awq_gemm
+    clear = native.clear_repack_cache if binding == "native" else ops.clear_repack_cache
+    M, K, N, G = 4, 256, 128, 128
+    x_np, qw_np, s_np, qz_np = orc.make_inputs(M, K, N, G, seed=31)
+    _, qw2_np, s2_np, qz2_np = orc.make_inputs(M, K, N, G, seed=32)
+
+    def want(qw_, s_, qz_):
+        return orc.gemm_faithful(x_np, qw_, s_, qz_).astype(np.float32)
+
+    with torch.inference_mode():
+        x, qw, s, qz = [dev_t(a, cuda) for a in (x_np, qw_np, s_np, qz_np)]
+        assert qw.is_inference() and s.is_inference()
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            y1 = gemm(x, qw, s, qz, 8)
+            n0 = native.repack_count()
+            y1b = gemm(x, qw, s, qz, 8)
+        assert torch.equal(y1, y1b)
+        if binding == "native":
+            assert native.repack_count() == n0 + 1  # re-packed again: nothing was kept
+        else:
+            assert any("inference-mode" in str(w.message) for w in seen) or ops._warned_untracked
+        assert np.allclose(y1.float().cpu().numpy(), want(qw_np, s_np, qz_np), rtol=1e-2, atol=1e-3)
+        # reload in place, same storage, under inference mode: the next call must see the new weights
+        qw.copy_(dev_t(qw2_np, cuda)), s.copy_(dev_t(s2_np, cuda)), qz.copy_(dev_t(qz2_np, cuda))
+        y2 = gemm(x, qw, s, qz, 8)
+        assert np.allclose(y2.float().cpu().numpy(), want(qw2_np, s2_np, qz2_np), rtol=1e-2, atol=1e-3)
+        assert not torch.equal(y1, y2)
+    # normal tensors written through .data (counter untouched): right again once the cache was cleared
+    x, qw, s, qz = [dev_t(a, cuda) for a in (x_np, qw_np, s_np, qz_np)]
+    y1 = gemm(x, qw, s, qz, 8)
+    v = qw._version
+    qw.data.copy_(dev_t(qw2_np, cuda)), s.data.copy_(dev_t(s2_np, cuda)), qz.data.copy_(dev_t(qz2_np, cuda))
+    assert qw._version == v  # which is why the cache cannot see it
+    clear()
+    y2 = gemm(x, qw, s, qz, 8)
+    assert np.allclose(y2.float().cpu().numpy(), want(qw2_np, s2_np, qz2_np), rtol=1e-2, atol=1e-3)
+    assert not torch.equal(y1, y2)

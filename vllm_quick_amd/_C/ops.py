@@ -499,11 +499,16 @@ def awq_gemm_stock(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors
 
 # Repack cache for callers that hand over stock tensors on every call (the
 # reference signature).  An entry is reused only for the very same tensor
-# objects at the same version counters, so in-place weight loading, freed and
-# re-used addresses and fresh views all miss and re-pack.
+# objects at the same version counters, so in-place writes PyTorch counts,
+# freed and re-used addresses and fresh views all miss and re-pack.  Two kinds
+# of write are invisible to a version counter: writes through `param.data`
+# (the reference's loaders: call clear_repack_cache(), or mark_written() on this
+# package's layers, after such a load that follows a first call), and writes to
+# tensors created under torch.inference_mode(), which keep no counter at all:
+# nothing is cached for those (every call re-packs, warned about once).
 def tensor_version(t: torch.Tensor) -> int:
-    """In-place-write counter of a tensor; inference-mode tensors keep none (they cannot be written in place
-    outside inference mode anyway), so those report 0."""
+    """In-place-write counter of a tensor; inference-mode tensors keep none and report 0 (`_cached_pack` never
+    keeps an entry for them)."""
     try:
         return t._version
     except RuntimeError:
@@ -525,12 +530,24 @@ class _CacheEntry:
 
 _repack_cache: Dict[Tuple, _CacheEntry] = {}
 _CACHE_LIMIT = 4096
+_warned_untracked = False
 
 
 def _cached_pack(kernel, scaling_factors, zeros) -> Optional[PackedAWQ]:
     key = (kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), tuple(kernel.shape),
            scaling_factors.shape[0], kernel.device.index)
     tensors = (kernel, scaling_factors, zeros)
+    if any(t.is_inference() for t in tensors):
+        # no version counters: an in-place reload could not be told from no change, so nothing is kept
+        if stream_is_capturing():
+            return None
+        global _warned_untracked
+        if not _warned_untracked:
+            _warned_untracked = True
+            warnings.warn("awq_gemm: the weights are inference-mode tensors, which keep no version counter: they are "
+                          "re-ordered into the private layout on every call; create weights outside "
+                          "torch.inference_mode() to have that done once", RuntimeWarning, stacklevel=3)
+        return awq_repack(kernel, scaling_factors, zeros)
     entry = _repack_cache.get(key)
     if entry is not None and entry.matches(tensors):
         return entry.packed
@@ -543,6 +560,8 @@ def _cached_pack(kernel, scaling_factors, zeros) -> Optional[PackedAWQ]:
         if len(_repack_cache) >= _CACHE_LIMIT:
             _repack_cache.clear()
     packed = awq_repack(kernel, scaling_factors, zeros)
+    # once per layer: the copy is complete before a call on any other stream can find it in the cache
+    torch.cuda.current_stream(kernel.device).synchronize()
     _repack_cache[key] = _CacheEntry(tensors, packed)
     return packed
 

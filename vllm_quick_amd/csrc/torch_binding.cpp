@@ -11,12 +11,20 @@
 // awq_gemm is handed the STOCK tensors on every call.  The first call for a layer re-orders them once
 // into the library's private layout (w4a16_repack) and keeps the result in a process-wide table keyed
 // by the three storages; later calls go straight to the matrix-instruction kernels.  An entry is reused
-// only for the very same tensors at the same version counters, so in-place weight loading, freed and
-// re-used addresses and fresh views all miss and re-pack.  Nothing is re-ordered or allocated for the
-// table while the current stream is capturing a graph: such a call is served by the shape-agnostic
-// kernel on the stock layout (three to five times slower), counted in stock_kernel_calls() and warned about
-// once - run one eager warm-up call per layer before capturing, as vLLM does
-// (vllm/worker/model_runner.py:765-775).
+// only for the very same tensors at the same version counters, so in-place writes PyTorch counts
+// (copy_, add_, ... on the tensor itself), freed and re-used addresses and fresh views all miss and
+// re-pack.  Two kinds of write are invisible to a version counter:
+//  * writes through `param.data` (the reference's weight loaders: `param.data.copy_(..)` leaves
+//    `param._version` alone): after such a load that follows a first call, the caller must call
+//    clear_repack_cache() (the layers of this package do the equivalent in their own loaders);
+//  * tensors created under torch.inference_mode() keep no counter at all: their packed copies are NOT kept
+//    (every call re-packs, warned about once), so an in-place reload is always seen.
+// The re-layout runs on the stream of the call that needs it, and that stream is synchronised once before
+// the entry becomes visible: calls on other streams never see a half-written copy.
+// Nothing is re-ordered or allocated for the table while the current stream is capturing a graph: such
+// a call is served by the shape-agnostic kernel on the stock layout (three to five times slower), counted
+// in stock_kernel_calls() and warned about once - run one eager warm-up call per layer before capturing,
+// as vLLM does (vllm/worker/model_runner.py:765-775).
 #include <ATen/hip/HIPContext.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -78,7 +86,7 @@ Geometry geometry(const torch::Tensor& kernel, const torch::Tensor& scaling_fact
 }
 
 uint32_t version_of(const torch::Tensor& t) {
-  // inference-mode tensors carry no version counter (they cannot be written in place outside inference mode)
+  // (inference-mode tensors carry no version counter: packed_for never keeps an entry for them)
   return t.is_inference() ? 0u : t._version();
 }
 
@@ -127,6 +135,23 @@ bool capturing(hipStream_t s) {
 std::shared_ptr<Packed> packed_for(const torch::Tensor& kernel, const torch::Tensor& scaling_factors,
                                    const torch::Tensor& zeros, const Geometry& g, hipStream_t stream) {
   const torch::Tensor* src[3] = {&kernel, &scaling_factors, &zeros};
+  // Without version counters an in-place reload cannot be told from no change: nothing is kept for such tensors.
+  const bool trackable = !(kernel.is_inference() || scaling_factors.is_inference() || zeros.is_inference());
+  if (!trackable) {
+    if (capturing(stream)) return nullptr;
+    TORCH_WARN_ONCE(
+        "awq_gemm: the weights are inference-mode tensors, which keep no version counter: they are re-ordered "
+        "into the private layout on every call; create weights outside torch.inference_mode() to have that done once");
+    const size_t wbytes = w4a16_packed_weight_bytes(g.K, g.N), sbytes = w4a16_packed_sz_bytes(g.K, g.N, g.G);
+    if (wbytes == 0 || sbytes == 0) throw std::invalid_argument("cannot repack these shapes");
+    const auto opts = torch::TensorOptions().dtype(torch::kUInt8).device(kernel.device());
+    auto pw = torch::empty({(int64_t)wbytes}, opts), ps = torch::empty({(int64_t)sbytes}, opts);
+    raise_for(w4a16_repack(kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), pw.data_ptr(), ps.data_ptr(),
+                           g.K, g.N, g.G, stream),
+              "awq_gemm (repack)");
+    ++g_repacks;
+    return std::make_shared<Packed>(std::move(pw), std::move(ps), src);  // used on this stream, then dropped
+  }
   const Key key{kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), kernel.size(0), kernel.size(1),
                 scaling_factors.size(0), (int)kernel.get_device()};
   std::lock_guard<std::mutex> lock(g_mutex);
@@ -145,6 +170,8 @@ std::shared_ptr<Packed> packed_for(const torch::Tensor& kernel, const torch::Ten
                          g.K, g.N, g.G, stream),
             "awq_gemm (repack)");
   ++g_repacks;
+  // once per layer: the copy is complete before any other stream can find it in the table
+  TORCH_CHECK(hipStreamSynchronize(stream) == hipSuccess, "awq_gemm (repack): hipStreamSynchronize failed");
   auto entry = std::make_shared<Packed>(std::move(pw), std::move(ps), src);
   g_table[key] = entry;
   return entry;
