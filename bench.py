@@ -573,7 +573,12 @@ def main():
             del col, row
             torch.cuda.empty_cache()
             from benchmarks.llama_decode import run as decode_run
-            out["decode"] = decode_run("7b", (1, 8, 64), device=device)
+            out["decode"] = decode_run("7b", (1, 8, 64), device=device, keep_stock=False)
+            torch.cuda.empty_cache()
+            # compute half of the TP=8 metric: one rank's step of the Llama-2-70B-shaped model (8 of 80 layers run,
+            # extrapolated), every all-reduce a device copy of the same size; a run on 8 GPUs adds the collectives
+            out["decode_tp8_rank_compute"] = decode_run("70b", (1, 8, 64), n_layers=8, device=device, keep_stock=False,
+                                                        rehearse_tp=8)
             torch.cuda.empty_cache()
             # small-M batched path: Mixtral-8x7B-shaped expert block, batched launches vs per-expert loop
             from benchmarks.mixtral_experts import run as experts_run

@@ -227,11 +227,15 @@ def time_graph(fn, stream, reps=20):
 
 
 def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ctx_len=128, device=None,
-        fuse_act=True, fuse_add=True, keep_stock=True):
+        fuse_act=True, fuse_add=True, keep_stock=True, rehearse_tp=0):
+    """`rehearse_tp` = N > 1 on a single process: the step of ONE rank of an N-way tensor-parallel model (layers
+    sharded as rank 0's, every all-reduce a device copy of the same size): the compute half of a tensor-parallel
+    step, to which a run on N GPUs adds the collectives."""
     cfg = SHAPES[model_name]
     device = device or torch.device("cuda", torch.cuda.current_device())
     n_layers = n_layers or cfg["layers"]
-    with torch.inference_mode():
+    rehearsal = ps.rehearse_one_rank(rehearse_tp) if rehearse_tp > 1 else contextlib.nullcontext()
+    with torch.inference_mode(), rehearsal:
         model = Model(cfg, n_layers, max(batch_sizes), ctx_len + 8, device, keep_stock=keep_stock)
         for layer in model.layers:
             layer.fuse_act = fuse_act
@@ -254,10 +258,14 @@ def run(model_name="7b", batch_sizes=(1, 2, 4, 8, 16, 32, 64), n_layers=None, ct
                 "w4a16_share": ms_lin / ms,
             }
     return {"model": f"llama-2-{model_name}-awq-shaped (synthetic weights, g128)", "layers_run": n_layers,
-            "layers_model": cfg["layers"], "context": ctx_len, "tp": ps.get_tensor_model_parallel_world_size(),
+            "layers_model": cfg["layers"], "context": ctx_len,
+            "tp": rehearse_tp if rehearse_tp > 1 else ps.get_tensor_model_parallel_world_size(),
+            "ranks_run": 1 if rehearse_tp > 1 else ps.get_tensor_model_parallel_world_size(),
+            "all_reduce": "a device copy of the same size (one rank run alone)" if rehearse_tp > 1 else None,
             "gate_up_activation": "fused into the GEMM epilogue" if fuse_act else "separate elementwise ops",
             "residual_add": "fused into the o_proj / down_proj GEMM epilogue (one rank)" if fuse_add else "separate op",
             "quantised_weight_bytes_resident": int((bytes_both - released) * cfg["layers"] / n_layers),
+            "quantised_weight_bytes_with_stock_tensors": int(bytes_both * cfg["layers"] / n_layers),
             "stock_tensors": "kept beside the private layout" if keep_stock else "released after re-ordering",
             "by_batch": res}
 

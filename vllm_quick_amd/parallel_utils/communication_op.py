@@ -14,7 +14,7 @@ import torch.distributed as dist
 from .custom_all_reduce import custom_all_reduce
 from . import rccl_utils
 from .parallel_state import (get_tensor_model_parallel_group, get_tensor_model_parallel_world_size,
-                             is_rccl_enabled_for_all_reduce)
+                             is_rccl_enabled_for_all_reduce, rehearsing_one_rank)
 
 
 def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
@@ -22,6 +22,8 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     and use the return value (communication_op.py:17-41)."""
     if get_tensor_model_parallel_world_size() == 1:
         return input_
+    if rehearsing_one_rank():
+        return input_.clone()  # one rank alone (parallel_state.rehearse_one_rank): a device copy of the same size
     out = custom_all_reduce(input_)
     if out is not None:
         return out

@@ -47,15 +47,44 @@ def get_tensor_model_parallel_group() -> Optional[dist.ProcessGroup]:
 
 
 def get_tensor_model_parallel_world_size() -> int:
+    if _REHEARSED is not None:
+        return _REHEARSED[0]
     if _TP_GROUP is None:
         return 1
     return dist.get_world_size(group=_TP_GROUP)
 
 
 def get_tensor_model_parallel_rank() -> int:
+    if _REHEARSED is not None:
+        return _REHEARSED[1]
     if _TP_GROUP is None:
         return 0
     return dist.get_rank(group=_TP_GROUP)
+
+
+# One rank's share of a tensor-parallel model on a single process, for measuring the compute half of a step
+# without the other ranks: layers built inside the block shard as rank `rank` of `world` would, and
+# `tensor_model_parallel_all_reduce` becomes a device copy of the same size (no sum: results are one rank's
+# partial products, good for timing only).
+_REHEARSED: Optional[tuple] = None
+
+
+@contextlib.contextmanager
+def rehearse_one_rank(world: int, rank: int = 0):
+    global _REHEARSED
+    if _TP_GROUP is not None:
+        raise AssertionError("a tensor model parallel group is initialized: nothing to rehearse")
+    if not 0 <= rank < world:
+        raise ValueError("rank must be in [0, world)")
+    prev, _REHEARSED = _REHEARSED, (world, rank)
+    try:
+        yield
+    finally:
+        _REHEARSED = prev
+
+
+def rehearsing_one_rank() -> bool:
+    return _REHEARSED is not None
 
 
 def get_tensor_model_parallel_src_rank() -> int:
