@@ -304,6 +304,9 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
  *                                                   (splits = 1 unless a workspace lets K be split over workgroups)
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
  *                DECODE      (1, t, waves, splits)  up to 16 rows
+ * w4a16_launch_shape takes no group size: it answers for a group size the decode kernel admits (32, 64 or a
+ * multiple of 128, i.e. every AWQ checkpoint in use); for another multiple of 32 the launches it reports as
+ * DECODE are made by the streaming kernel with the same (t, waves).  w4a16_launch_shape_ws takes the group size.
  */
 enum { W4A16_KERNEL_STREAMING = 0, W4A16_KERNEL_LDS_STAGED = 1, W4A16_KERNEL_MFMA32 = 2, W4A16_KERNEL_MFMA32_SHARED = 3,
        W4A16_KERNEL_DECODE = 4 };

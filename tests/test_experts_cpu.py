@@ -140,13 +140,19 @@ def test_stamp_cache_and_invalidation(monkeypatch):
     mark_written(lin.qweight)
     moe(x)
     assert count() == 4
-    # a tensor swapped behind the counters' back needs invalidate()
+    # a tensor whose storage was swapped (`param.data = ..`, what `module.to(..)` does): seen by its address
     lin.scales.data = lin.scales.data.clone()
     moe(x)
-    assert count() == 4
-    moe.invalidate()
+    assert count() == 6
     moe(x)
     assert count() == 6
+    # a write through `.data` into the same storage touches neither address nor counter: that needs invalidate()
+    lin.scales.data.copy_(lin.scales.data * 2)
+    moe(x)
+    assert count() == 6
+    moe.invalidate()
+    moe(x)
+    assert count() == 8
 
 
 def test_both_routes_combine_the_experts_the_same_way(monkeypatch):

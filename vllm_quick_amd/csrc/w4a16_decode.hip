@@ -312,6 +312,13 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     // Partial sums and tickets travel as device-scope atomic accesses (each one coherent across the XCDs'
     // L2s by itself), ordered by the wave's own completion counter: a device-scope fence would write back and
     // invalidate a whole L2 per workgroup (~50 ns each, serialised: 69 us on a 1376-workgroup launch).
+    // What this rests on, beyond the language's memory model (relaxed accesses promise no order between
+    // the stores and the ticket): on gfx950 a device-scope store (`global_store .. sc1`) goes through to memory
+    // and leaves the wave's vmcnt only once it is acknowledged there, so after `s_waitcnt vmcnt(0)` this wave's
+    // sums are visible to every XCD before its ticket is drawn; the last arriver's loads (`.. sc1`: served
+    // past its CU's cache) are issued by the very wave whose returning atomic told it that it is last, after
+    // the value is back; and the compiler keeps relaxed atomic loads behind the branch on that value.  Only
+    // this one wave of a workgroup stores, signals and loads.
     float* all = reinterpret_cast<float*>(ws + slot * S * SLOT);
     auto put = [&](int idx, f32x4 r) {
 #pragma unroll

@@ -110,20 +110,23 @@ class MixtralMoE(torch.nn.Module):
 
     def invalidate(self) -> None:
         """Forget the packed copy (after a write to an expert's tensors that neither went through a weight
-        loader nor bumped the tensor's in-place-write counter, e.g. `param.data = ...`)."""
+        loader, nor bumped the tensor's in-place-write counter, nor moved its storage: `param.data.copy_(..)`,
+        an in-place write to an inference-mode tensor)."""
         self._packed = None
 
     def _versions(self):
+        """Address and in-place-write counter of every watched tensor: a storage swap (`param.data = ..`,
+        `module.to(..)`) changes the first, a counted in-place write the second."""
         try:
-            return tuple(t._version for t in self._watched)
-        except RuntimeError:  # inference tensors keep no counter (and cannot be written in place)
-            return None
+            return tuple((t.data_ptr(), t._version) for t in self._watched)
+        except RuntimeError:  # inference tensors keep no counter
+            return tuple((t.data_ptr(), 0) for t in self._watched)
 
     def _batches(self):
         """The local experts' weights back to back in the private layout, rebuilt when any stock
-        tensor was written since (weight loading).  The common case costs one integer comparison and one
-        pass over the tensors' write counters: the full look at every tensor (its address too) is taken
-        only after a weight loader has run."""
+        tensor was written since (weight loading) or moved.  The common case costs one integer comparison
+        and one pass over the watched tensors' addresses and write counters: the experts' modules are walked
+        again only after a weight loader has run or one of those changed."""
         if self._packed is not None and self._packed[0] == (write_epoch(), self.fuse_act, self._versions()):
             return self._packed[1], self._packed[2]
         w1, w3, w2 = self._stock(("w1", )), self._stock(("w3", )), self._stock(("w2", ))
