@@ -196,6 +196,17 @@ __device__ unsigned long long g_stamps[4096 * 32];
 #else
 #define STAMP(slot) do {} while (0)
 #endif
+// Diagnostic build of ONE kernel translation unit (-DW4A16_STAMPS on that file alone, the others as shipped): that
+// file's stamp buffer is read through this accessor, which each kernel file expands at its end.  (With every file
+// built as one unit, -DW4A16_UNITY on w4a16.hip, the accessor lives there.)
+#if defined(W4A16_STAMPS) && !defined(W4A16_UNITY)
+#define W4A16_STAMPS_ACCESSOR                                                                                          \
+  extern "C" int w4a16_dbg_stamps(void* host_out, size_t bytes) {                                                      \
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w4a16::g_stamps), bytes, 0, hipMemcpyDeviceToHost);           \
+  }
+#else
+#define W4A16_STAMPS_ACCESSOR
+#endif
 // A compile-time switch passed as a lambda argument.
 template <int V>
 struct Flag {
@@ -451,11 +462,21 @@ inline bool decode_built(int t, int waves, bool act) {
   return false;
 }
 
+// The 8-wave shapes with two 32-row tiles run the two waves of a SIMD half a block apart (see the kernel): the
+// conversion is half of such a wave's issue slots, and a wave that converts while its partner is at the barrier keeps
+// the matrix pipe fed (measured on 4096 x 11008: 2 to 7 % at 512 to 4096 rows).  With four row tiles the matrix
+// instructions dominate either way and the stagger measured 0 to -1 %: those keep the plain loop.
+#ifndef W4A16_STAGGER
+#define W4A16_STAGGER 1
+#endif
+template <int MT, int T, int NW>
+constexpr bool wide_shared_staggered() { return W4A16_STAGGER && NW == 8 && MT == 2; }
 // Slabs in the ring of gemm_wide_shared_kernel: three (the DMA runs two blocks ahead) for workgroups that have a CU to
 // themselves; two for the 4-wave shape that leaves registers and LDS for a second workgroup on the CU, whose
-// arithmetic then covers the first one's waits, prologue and stores.
+// arithmetic then covers the first one's waits, prologue and stores; four for the staggered shapes, where a slab is
+// read for two barrier intervals.
 template <int MT, int T, int NW>
-constexpr int ring_slabs() { return (NW == 4 && MT * T <= 8) ? 2 : 3; }
+constexpr int ring_slabs() { return wide_shared_staggered<MT, T, NW>() ? 4 : (NW == 4 && MT * T <= 8) ? 2 : 3; }
 
 // One dispatcher per kernel family, each defined in that family's translation unit: launch shape -> instantiation.
 W4A16_HIDDEN int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1,

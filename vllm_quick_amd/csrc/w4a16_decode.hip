@@ -464,3 +464,5 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
 }
 
 }  // namespace w4a16
+
+W4A16_STAMPS_ACCESSOR

@@ -335,3 +335,5 @@ int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, 
 
 
 }  // namespace w4a16
+
+W4A16_STAMPS_ACCESSOR

@@ -352,3 +352,5 @@ int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t
 
 
 }  // namespace w4a16
+
+W4A16_STAMPS_ACCESSOR

@@ -539,12 +539,7 @@ int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int b
 
 }  // namespace w4a16
 
-#if defined(W4A16_STAMPS) && !defined(W4A16_UNITY)
-// Diagnostic build of this translation unit alone (-DW4A16_STAMPS): copies its stamp buffer to host memory.
-extern "C" int w4a16_dbg_stamps(void* host_out, size_t bytes) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w4a16::g_stamps), bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif
+W4A16_STAMPS_ACCESSOR
 
 #ifdef W4A16_CHECK_DMA
 // Checking build: reads {fragments that overtook their DMA, skip-waits switch}; `set_skip` >= 0 writes the switch and

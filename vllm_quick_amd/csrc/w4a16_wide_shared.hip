@@ -20,8 +20,8 @@ namespace {
 // matrix instruction.  Here the NW waves of a workgroup each own T 32-column tiles for all MT 32-row
 // tiles over the WHOLE of K (no K split, so no cross-wave reduction: results go from the accumulators
 // straight to memory), and share the [32 MT rows] x [128 k] activation slab of the current block, which
-// the waves fetch together by LDS-DMA into a ring of three slabs (256-byte rows, 16-byte chunks
-// XOR-swizzled by the row), two blocks ahead.  A weight fragment converted once feeds MT matrix
+// the waves fetch together by LDS-DMA into a ring of slabs (two to four, see ring_slabs(); 256-byte rows, 16-byte
+// chunks XOR-swizzled by the row), two blocks ahead.  A weight fragment converted once feeds MT matrix
 // instructions: with MT = 4 the conversion takes a quarter of the vector issue slots of the 16x16x32
 // kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
 // landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   constexpr int NSZ = 4 / SZS;
   constexpr int WL = T * (NSZ + 2);         // register loads per weight block and wave
   constexpr int RING = ring_slabs<MT, T, NW>();
+  constexpr bool STG = wide_shared_staggered<MT, T, NW>();  // the waves of a SIMD run half a block apart
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int lane = threadIdx.x & 63;
@@ -168,6 +169,26 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
       __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
     }
   };
+  // Four k-steps (half HB of a block) from weight set `b`.  On entry `xa` holds the fragments of the half's first
+  // k-step and `af0` tile 0's converted weights for it; on exit `af0` holds tile 0's weights of the k-step that
+  // follows the half (if the block has one): the conversion runs one tile ahead of the matrix instructions.
+  auto half = [&](auto hb_, int base, const WSet& b, SZ (&c)[T], f16x8& af0, f16x8 (&xa)[MT]) {
+    constexpr int K0 = 4 * decltype(hb_)::value;
+    f16x8 xb[MT];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2 += 2) {
+      read_x(K0 + k2 + 1, base, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      math(K0 + k2, b, c, xa, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 == 0) read_x(K0 + 2, base, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      math(K0 + k2 + 1, b, c, xb, af0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const int n = a.KB;  // >= 2 (host-checked)
+  if constexpr (!STG) {
   // Block i from weight set `cur` in ring slab i % 3.  A wave's vector-memory operations, in issue order:
   //   D(0), D(1), W(0) | D(2), W(1) | D(3), W(2) | ..      (D = its ND DMA loads of a slab, W = WL loads)
   // one group per block, issued right after the block's barrier.  Before the barrier of block i the wave's
@@ -202,7 +223,6 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     }
   };
 
-  const int n = a.KB;  // >= 2 (host-checked)
   WSet w0, w1;
   dma_x(0, 0);
   if constexpr (RING == 3) dma_x(1, 1);
@@ -221,6 +241,111 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   }
   block(Flag<RING == 2>{}, Flag<1>{}, i, w0, w1);  // (two slabs: the last block's slab is still to be fetched)
   block(Flag<0>{}, Flag<0>{}, i + 1, w1, w0);
+
+  } else {
+    // Staggered: the two waves of a SIMD (w and w + NW / 2) run half a block apart, so that one is in the middle of
+    // its matrix instructions while the other passes the barrier, requests its loads and converts its first
+    // fragment.  Between barrier j and barrier j + 1 the waves of the first half (A) work through block j; those of
+    // the second half (B) finish block j - 1 (its k-steps 4-7) and start block j (k-steps 0-3).  Block j's slab is
+    // thus read until barrier j + 2, and the DMA issued behind barrier j (for block j + 2) goes to the slot of
+    // block j - 2: a ring of four.  Every wave still fetches its share of every slab.  A wave's vector-memory
+    // operations, in issue order:  D(0), D(1), W(0) | D(2), W(1) | D(3), W(2) | ..   (one group per barrier; B
+    // issues W(j + 1) in the middle of the interval, once the set of block j - 1 is free).  Before barrier j the
+    // wave's share of D(j) must have landed: all but the youngest ND + WL (D(j + 1), W(j)); WL where D(j + 1)
+    // does not exist.
+    static_assert(RING == 4 && NW % 2 == 0, "ring of four slabs");
+    auto slab_of = [&](int j) { return (j & 3) * SLAB + xrd; };
+    WSet w0, w1;
+    dma_x(0, 0);
+    dma_x(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (w < NW / 2) {
+      // ---- A: whole blocks, as the unstaggered loop ----
+      auto block_a = [&](auto dma, auto lw, int j, const WSet& cur, WSet& nxt) {
+        constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
+        W4A16_DMA_WAIT(LW ? ND + WL : WL);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) dma_x(j + 2, (j + 2) & 3);
+        __builtin_amdgcn_sched_barrier(0);  // the wait counts rely on this issue order: DMA first, then weights
+        if constexpr (LW) load_w(j + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int base = slab_of(j);
+        SZ c[T];
+        f16x8 xa[MT];
+        read_x(0, base, xa);
+        f16x8 af0 = convert(0, 0, cur, c);
+        half(Flag<0>{}, base, cur, c, af0, xa);
+        read_x(4, base, xa);
+        half(Flag<1>{}, base, cur, c, af0, xa);
+      };
+      int j = 0;
+      for (; j + 2 <= n - 2; j += 2) {
+        block_a(Flag<1>{}, Flag<1>{}, j, w0, w1);
+        block_a(Flag<1>{}, Flag<1>{}, j + 1, w1, w0);
+      }
+      if (j < n - 2) {
+        block_a(Flag<1>{}, Flag<1>{}, j, w0, w1);
+        w0 = w1;
+        ++j;
+      }
+      block_a(Flag<0>{}, Flag<1>{}, j, w0, w1);
+      block_a(Flag<0>{}, Flag<0>{}, j + 1, w1, w0);
+    } else {
+      // ---- B: half a block behind: the barriers fall in the middle of its blocks ----
+      // Block b: W(b + 1) requested, k-steps 0-3, barrier b + 1 (behind it the DMA for block b + 3), k-steps 4-7.
+      // BAR: barrier b + 1 and W(b + 1) exist (b + 1 < n); NXT: D(b + 2) exists; DMA: D(b + 3) exists.  Before barrier
+      // b + 1 this wave's share of D(b + 1) has landed once all but the youngest ND + WL (D(b + 2), W(b + 1)) are done.
+      auto block_b = [&](auto bar, auto nxt_, auto dma, int b, const WSet& cur, WSet& nxt) {
+        constexpr bool BAR = decltype(bar)::value, NXT = decltype(nxt_)::value, DMA = decltype(dma)::value;
+        constexpr bool LW = BAR;
+        if constexpr (LW) load_w(b + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int base = slab_of(b);
+        SZ c[T];
+        f16x8 xa[MT];
+        read_x(0, base, xa);
+        f16x8 af0 = convert(0, 0, cur, c);
+        half(Flag<0>{}, base, cur, c, af0, xa);
+        if constexpr (BAR) {
+          W4A16_DMA_WAIT(NXT ? ND + WL : WL);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (DMA) dma_x(b + 3, (b + 3) & 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        read_x(4, base, xa);
+        half(Flag<1>{}, base, cur, c, af0, xa);
+      };
+      // barrier 0, behind it the DMA for block 2
+      W4A16_DMA_WAIT(ND + WL);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (n == 2) {  // no block 2: both slabs were requested in the prologue
+        block_b(Flag<1>{}, Flag<0>{}, Flag<0>{}, 0, w0, w1);
+        block_b(Flag<0>{}, Flag<0>{}, Flag<0>{}, 1, w1, w0);
+      } else {
+        dma_x(2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // blocks 0 .. n - 4 have a block three ahead to fetch; then b = n - 3 (no DMA), n - 2 (no DMA), n - 1 (no barrier)
+        int b = 0;
+        for (; b + 2 <= n - 3; b += 2) {
+          block_b(Flag<1>{}, Flag<1>{}, Flag<1>{}, b, w0, w1);
+          block_b(Flag<1>{}, Flag<1>{}, Flag<1>{}, b + 1, w1, w0);
+        }
+        if (b < n - 3) {
+          block_b(Flag<1>{}, Flag<1>{}, Flag<1>{}, b, w0, w1);
+          w0 = w1;
+          ++b;
+        }
+        block_b(Flag<1>{}, Flag<1>{}, Flag<0>{}, b, w0, w1);      // b = n - 3
+        block_b(Flag<1>{}, Flag<0>{}, Flag<0>{}, b + 1, w1, w0);  // b = n - 2
+        block_b(Flag<0>{}, Flag<0>{}, Flag<0>{}, b + 2, w0, w1);  // b = n - 1
+      }
+    }
+  }
 
   // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
 #pragma unroll
@@ -263,7 +388,7 @@ template <int MT, int T, int NW>
 int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   constexpr int lds = ring_slabs<MT, T, NW>() * MT * 32 * 256;  // ring of slabs
   static_assert(lds <= 160 * 1024, "LDS budget");
-  // whole 128-k blocks, at least two of them, and 32-bit byte offsets into the three buffers
+  // whole 128-k blocks, at least two of them, and 32-bit byte offsets
   if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
     return W4A16_E_SHAPE;
   if (act && a.N % 32) return W4A16_E_SHAPE;
