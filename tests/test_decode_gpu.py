@@ -250,7 +250,9 @@ def test_library_choice_with_a_workspace(L, ops, cuda):
     assert L.lib.w4a16_workspace_bytes(1, K, N, G, 1, 0) > 65536
     assert L.lib.w4a16_workspace_bytes(1, 4096, 11008, G, 1, 0) == 0   # enough column tiles: no split
     assert L.lib.w4a16_workspace_bytes(1, 8192, 1280, G, 1, 0) == 0    # K too short for a split to pay
-    assert L.lib.w4a16_workspace_bytes(64, K, N, G, 1, 0) == 0
+    # 64 rows of this layer: the private-slab 32x32x16 kernel splits K over workgroups too (tickets + partial sums)
+    assert L.lib.w4a16_workspace_bytes(64, K, N, G, 1, 0) > 65536
+    assert L.lib.w4a16_workspace_bytes(512, K, N, G, 1, 0) == 0  # many rows: nothing is split
     ws = ops.gemm_workspace(cuda)
     for M in (1, 4):
         x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=11 + M)
