@@ -33,13 +33,14 @@ rc = lib.w4a16_dbg_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b
 assert rc == 0, rc
 st = buf.reshape(-1, 32)[: min(ctas * kw, 4096)].astype(np.int64)
 wid = np.arange(len(st)) % kw
-keep = st[:, 23] > 0
-st, wid = st[keep], wid[keep]
+keep = st[:, 20] > 0
+full = st[:, 23] > 0
+st, wid, full = st[keep], wid[keep], full[keep]
 t0 = st[:, 0].min()
 def stat(name, v):
     print(f"{name:34s} min {v.min():8.0f}  med {np.median(v):8.0f}  max {v.max():8.0f}")
 print(f"wide ({mt},{t},{kw}) M={M} {K}x{N}: {len(st)} waves stamped")
-clk = (st[:, 23] - st[:, 0]) / np.maximum(st[:, 31] - st[:, 30], 1) * 100.0
+clk = ((st[:, 23] - st[:, 0]) / np.maximum(st[:, 31] - st[:, 30], 1) * 100.0)[full]
 stat("clock MHz (cycles / 100 MHz ticks)", clk)
 stat("start skew", st[:, 0] - t0)
 stat("setup + first requests", st[:, 1] - st[:, 0])
@@ -48,7 +49,7 @@ stat("  -> offsets, accumulators zeroed", st[:, 25] - st[:, 24])
 stat("  -> first weight block requested", st[:, 26] - st[:, 25])
 stat("  -> half slab 0 requested", st[:, 27] - st[:, 26])
 stat("  -> half slab 1 requested", st[:, 1] - st[:, 27])
-nblk = -(-(-(-(-(-K // 128)) // splits)) // kw)
+nblk = -(-(-(-(-(-K // 128)) // splits)) // kw) + (1 if kw == 8 else 0)
 prev = st[:, 1]
 for b in range(min(nblk, 16)):
     cur = st[:, 2 + b]
@@ -57,12 +58,12 @@ for b in range(min(nblk, 16)):
     prev = cur
 stat("main loop", st[:, 20] - st[:, 1])
 stat("wait at first barrier", st[:, 21] - st[:, 20])
-stat("fold / park partials", st[:, 22] - st[:, 21])
-stat("sum + store", st[:, 23] - st[:, 22])
-stat("wave lifetime", st[:, 23] - st[:, 0])
-print(f"first start -> last end: {st[:, 23].max() - t0} cycles")
+stat("fold / park partials", (st[:, 22] - st[:, 21])[full])
+stat("sum + store", (st[:, 23] - st[:, 22])[full])
+stat("wave lifetime", (st[:, 23] - st[:, 0])[full])
+stat("entry -> main loop done", st[:, 20] - st[:, 0])
 for wv in range(kw):
     sel = st[wid == wv]
     print(f" wave {wv}: first-req {np.median(sel[:, 1] - sel[:, 0]):6.0f} | blocks " +
           " ".join(f"{np.median(sel[:, 2 + b] - (sel[:, 1 + b] if b else sel[:, 1])):6.0f}" for b in range(min(nblk, 16))) +
-          f" | barrier {np.median(sel[:, 21] - sel[:, 20]):6.0f} fold {np.median(sel[:, 22] - sel[:, 21]):6.0f} store {np.median(sel[:, 23] - sel[:, 22]):6.0f}")
+          f" | loop-done@ {np.median(sel[:, 20] - sel[:, 0]):6.0f} barrier {np.median(sel[:, 21] - sel[:, 20]):6.0f} fold {np.median(sel[:, 22] - sel[:, 21]):6.0f} store {np.median(sel[:, 23] - sel[:, 22]):6.0f}")

@@ -133,7 +133,7 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false, bool hav
   // The 32x32x16 kernels read whole 128-k blocks through 32-bit byte offsets.  (With the fused activation a
   // tile is 16 gate + 16 up columns: as many tiles, and the same launch shapes, as the plain GEMM on N columns.)
   const bool wide_ok = K % 128 == 0 && (long long)NT * padded_kblocks(K) * 1024 < (1LL << 32) &&
-                       (long long)M * K < (1LL << 31);
+                       (long long)M * K * 2 + kDmaImmBias < (1LL << 32);
   // From 33 rows: 10-40 % faster than the 16x16x32 kernels on every layer shape measured, and ahead of
   // dequantise + dense GEMM at every row count.
   if (wide_ok && M > 32) return choose_mfma32(M, K, N, batch, have_ws);

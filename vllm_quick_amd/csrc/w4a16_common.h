@@ -87,10 +87,15 @@ __device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c, const DqC
   const f16x2 h1 = as_h2((w & k.hi) | k.magic);
   const f16x2 h2 = as_h2((t & k.lo) | k.magic);
   const f16x2 h3 = as_h2((t & k.hi) | k.magic);
-  const f16x2 d0 = (h0 + c.nz1) * c.s;
-  const f16x2 d1 = (h1 * k.sixteenth + c.nz2) * c.s;
-  const f16x2 d2 = (h2 + c.nz1) * c.s;
-  const f16x2 d3 = (h3 * k.sixteenth + c.nz2) * c.s;
+  // (stage by stage: a packed instruction right behind the one whose result it reads costs a wait state)
+  const f16x2 e0 = h0 + c.nz1;
+  const f16x2 e1 = h1 * k.sixteenth + c.nz2;
+  const f16x2 e2 = h2 + c.nz1;
+  const f16x2 e3 = h3 * k.sixteenth + c.nz2;
+  const f16x2 d0 = e0 * c.s;
+  const f16x2 d1 = e1 * c.s;
+  const f16x2 d2 = e2 * c.s;
+  const f16x2 d3 = e3 * c.s;
   return f16x8{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
 }
 
@@ -207,6 +212,9 @@ __device__ unsigned long long g_stamps[4096 * 32];
 #else
 #define W4A16_STAMPS_ACCESSOR
 #endif
+// LDS-DMA instructions that share an LDS base (M0) differ in their immediate offset (up to 4095), which moves the
+// LDS address and the source address alike; see the activations' buffer descriptor in the 32x32x16 kernels.
+constexpr uint32_t kDmaImmBias = 3072;
 // A compile-time switch passed as a lambda argument.
 template <int V>
 struct Flag {
@@ -217,7 +225,13 @@ struct Flag {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+#ifndef W4A16_WAIT_ASM
+  // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 (the other counters at
+  // their maximum: not waited for).  As a builtin the compiler's own wait-count bookkeeping sees it.
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 
 // Launch constants of the decode kernel the host works out once, so that the 16 waves of a workgroup, which
@@ -398,11 +412,19 @@ inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
 #define W4A16_FOR_EACH_TILED(X) \
   X(4, 3, 2, 4) X(4, 3, 4, 2) X(4, 3, 1, 4) X(4, 2, 2, 4) X(2, 3, 2, 4) X(2, 3, 1, 4) X(2, 3, 1, 8)
 // (mt, t, kw) of the 32x32x16 kernel with private slabs: mt, t in 32-row / 32-column tiles
+#ifndef W4A16_FOR_EACH_WIDE  // (kernel experiments build a single shape: -D'W4A16_FOR_EACH_WIDE(X)=X(2,3,4)')
 #define W4A16_FOR_EACH_WIDE(X) \
   X(2, 3, 8) X(2, 2, 8) X(2, 1, 8) X(1, 3, 8) X(1, 2, 8) X(2, 3, 4) X(2, 2, 4) X(1, 3, 4) X(4, 3, 4)
+#endif
 // Slices (1 KiB: 4 accumulator registers x 64 lanes) per owner wave in the private-slab kernel's final exchange, and
 // the workspace a K split over workgroups needs: the ticket region, then 4 owners x that many KiB per output tile
 // and split.
+// Private-slab shapes whose waves keep two whole activation slabs (the next block's arrives piece by piece during
+// the current one): 4 waves x two row tiles, 128 KiB of LDS.
+#ifndef W4A16_WIDE_DBL
+#define W4A16_WIDE_DBL 1
+#endif
+constexpr bool wide_double_slab(int mt, int kw) { return W4A16_WIDE_DBL && mt == 2 && kw == 4; }
 constexpr int wide_slices_per_owner(int mt, int t, bool act) { return act ? ((t * mt + 1) / 2) * 2 : t * mt; }
 inline size_t wide_ws_bytes(long long tiles, int splits, int mt, int t, bool act);
 // (mt, t, nw) of the shared-slab 32x32x16 kernel

@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   constexpr int XL = (W4A16_DBG & 1) ? 1 : XLR;
   constexpr int NSZ = 4 / SZS;           // scale/zero words per 128-k block and tile
   constexpr int WL = T * (NSZ + 2);      // register loads per weight block
+  // 4-wave shapes with two row tiles keep TWO whole slabs per wave (4 x 32 KiB of LDS) and fetch the next block's
+  // slab piece by piece, MT pieces per k-step, between the matrix instructions of the current block (see block2)
+  constexpr bool DBL = wide_double_slab(MT, KW) && !(W4A16_DBG & 1);
+  constexpr int WSLABS = DBL ? 2 : 1;    // slabs per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int lane = threadIdx.x & 63;
@@ -100,24 +104,13 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   for (int e = 0; e < 2; ++e) xchunk[e] = (lane & 7) ^ ((4 * e + (lane >> 4)) & 7);
 #pragma unroll
   for (int p = 0; p < XLR; ++p)
-    xoff[p] = ((uint32_t)min(m0 + 8 * p + (lane >> 3), a.M - 1) * a.K + xchunk[p & 1] * 8) * 2u;
-  const int wbase = w * SLAB;
-  // B fragment of k-step ks (0..3) of a half: row r32 (+ 32 mt), chunk 2 ks + h
+    xoff[p] = ((uint32_t)min(m0 + 8 * p + (lane >> 3), a.M - 1) * a.K + xchunk[p & 1] * 8) * 2u + kDmaImmBias;
+  const int wbase = w * (WSLABS * SLAB);
+  // Set up AFTER the wave's first requests are out (see below): the LDS addresses of the B fragments, the
+  // accumulators and the conversion's constants.
   int xrd[4];
-  {
-    const int f = (r32 >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xrd[ks] = wbase + r32 * 128 + (((2 * ks + h) ^ f) << 4);
-  }
-
   f32x16 acc[T][MT];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
-  const DqConst dqc = make_dq_const();
+  DqConst dqc;
   STAMP(25);
 
   struct WSet {
@@ -132,47 +125,62 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
   const __amdgpu_buffer_rsrc_t sz_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
-  const __amdgpu_buffer_rsrc_t x_rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  // (the activations' descriptor starts kDmaImmBias bytes BEFORE the matrix and every lane offset is larger by that
+  // much: a DMA instruction with an immediate offset then takes it off its lane offset without going below zero)
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<unsigned char*>(const_cast<f16*>(a.x)) - kDmaImmBias, 0, (int)((uint32_t)a.M * (uint32_t)a.K * 2u + kDmaImmBias), 0x00020000);
   auto load_w = [&](int kb, WSet& b) {
     if (W4A16_DBG & 2) kb = w;  // ablation: weights from cache
+    int goff[NSZ];  // (once per block, not per tile: the waves of a workgroup share one scalar unit)
+#pragma unroll
+    for (int s = 0; s < NSZ; ++s) goff[s] = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1) * 64;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int s = 0; s < NSZ; ++s) {
-        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
-        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
-      }
+      for (int s = 0; s < NSZ; ++s) b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], goff[s], 0);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
       b.q[t][1] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + 512, kb * 1024, 0);
     }
   };
-  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
-  // XL DMA loads: half hp of block kb's slab -> this wave's LDS half hp (K is a multiple of 128 here)
-  auto dma_x = [&](int kb, int hp) {
+  // DMA piece p (0 .. XLR - 1) of half hp of block kb's slab -> LDS half hp of this wave's slab `sl` (K is a multiple
+  // of 128 here)
+  auto dma_piece = [&](int kb, int hp, int p, int sl) {
+    const int dst = wbase + sl * SLAB + hp * HALF + p * 1024;
 #ifdef W4A16_CHECK_DMA
-#pragma unroll
-    for (int p = 0; p < XLR; ++p)
-      *reinterpret_cast<u32x4*>(smem_raw + wbase + hp * HALF + p * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
+    *reinterpret_cast<u32x4*>(smem_raw + dst + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pattern is in place before the DMA can land on it
 #endif
-#pragma unroll
-    for (int p = 0; p < XL; ++p)  // (ablation 1: XL is 1, an eighth of the activation traffic)
+    // The instruction's immediate offset (up to 4095) moves the LDS address AND the source address: pieces 4 j .. 4 j + 3
+    // share one LDS base (M0 is then written once per four pieces), their lane offsets are smaller by the same amount.
+    auto issue = [&](auto imm_) {  // (the immediate has to be a literal: p is a constant only after unrolling)
+      constexpr int IMM = decltype(imm_)::value;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + wbase + hp * HALF + p * 1024), 16, xoff[p],
-          (kb * 128 + hp * 64) * 2, 0, 0);
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + dst - IMM), 16, xoff[p] - (uint32_t)IMM,
+          (kb * 128 + hp * 64) * 2, IMM, 0);
+    };
+    switch (p & 3) {
+      case 0: issue(Flag<0>{}); break;
+      case 1: issue(Flag<1024>{}); break;
+      case 2: issue(Flag<2048>{}); break;
+      default: issue(Flag<3072>{}); break;
+    }
 #ifdef W4A16_CHECK_DMA
-    if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + wbase + hp * HALF + lane * 16), &g_dma_state[0]);
+    if (dma_skip_waits && p == 0) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + dst + lane * 16), &g_dma_state[0]);
 #endif
   };
+  // XL DMA loads: a whole half
+  auto dma_x = [&](int kb, int hp, int sl = 0) {
+#pragma unroll
+    for (int p = 0; p < XL; ++p) dma_piece(kb, hp, p, sl);  // (ablation 1: XL is 1, an eighth of the activation traffic)
+  };
   // B fragments of k-step `kstep` (0..7) of the block: 2 ds_read_b128 from half kstep / 4
-  auto read_x = [&](int kstep, f16x8 (&xf)[MT]) {
+  auto read_x = [&](int kstep, f16x8 (&xf)[MT], int sl = 0) {
     const int hp = kstep >> 2, ks = kstep & 3;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + hp * HALF + mt * 4096);
+      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + sl * SLAB + hp * HALF + mt * 4096);
 #ifdef W4A16_CHECK_DMA
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -259,6 +267,81 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 #endif
   };
 
+  // One k-step for block2: the same arithmetic tile by tile, each tile's matrix instructions and the next tile's
+  // conversion in a scheduling region of their own, and `between(t)` (a DMA piece) issued in program order behind
+  // tile t's region: right after a matrix instruction has started, so the piece goes out in its shadow.
+  auto math2 = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0, auto&& between) {
+    f16x8 af = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f16x8 nx = af;
+      if (t + 1 < T)
+        nx = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        nx = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+      constexpr int per = (13 + MT - 1) / MT;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {  // (the matrix instruction last: `between` then goes out in its shadow)
+        __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      af = nx;
+      __builtin_amdgcn_sched_barrier(0);
+      between(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    af0 = af;
+  };
+
+  // The same with two whole slabs per wave (DBL): block i reads slab i & 1 while the slab of the wave's next block
+  // arrives in the other one, MT pieces per k-step, each issued between the matrix instructions of that k-step: a
+  // burst of 8 DMA instructions from each of the four waves at once holds a wave's in-order issue for ~60 cycles per
+  // instruction (the CU's address path takes one 1-KiB instruction per ~16 cycles), a third of a block's time; one
+  // at a time they go out in the shadow of a matrix instruction.  Issue order per block: W(next), then the 2 XLR
+  // pieces (half 0 in k-steps 0-3, half 1 in 4-7).  Half 0 of the current slab was requested in k-steps 0-3 of the
+  // previous block: at the start all but the XLR + WL youngest operations must be done (XLR in the last block);
+  // half 1 is first read after k-step 2, when 3 MT pieces of this block are out: all but the 3 MT + WL youngest
+  // (none in the last block).
+  auto block2 = [&](auto last_, auto sl_, int kb_next, const WSet& cur, WSet& nxt) {
+    constexpr bool LAST = decltype(last_)::value != 0;
+    constexpr int SL = decltype(sl_)::value;
+    SZ c[T];
+    f16x8 xa[MT], xb[MT];
+    if constexpr (!LAST) {
+      load_w(kb_next, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    W4A16_DMA_WAIT(LAST ? XLR : XLR + WL);
+    read_x(0, xa, SL);
+    f16x8 af0 = convert(0, 0, cur, c);
+    // piece j (0 .. MT - 1) of k-step `kstep`: pieces 0 .. XLR - 1 fill half 0, the rest half 1
+    auto piece = [&](int kstep, int j) {
+      if constexpr (!LAST) {
+        if (j < MT) {
+          const int q = kstep * MT + j;
+          dma_piece(kb_next, q / XLR, q % XLR, SL ^ 1);
+        }
+      }
+    };
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2 += 2) {
+      read_x(k2 + 1, xb, SL);
+      __builtin_amdgcn_sched_barrier(0);
+      math2(k2, cur, c, xa, af0, [&](int t) { piece(k2, t); });
+      if (k2 + 1 == 3) W4A16_DMA_WAIT(LAST ? 0 : WL + 3 * MT);
+      if (k2 + 2 < 8) read_x(k2 + 2, xa, SL);
+      __builtin_amdgcn_sched_barrier(0);
+      math2(k2 + 1, cur, c, xb, af0, [&](int t) { piece(k2 + 1, t); });
+    }
+#ifdef W4A16_STAMPS
+    STAMP(2 + min(n_done, 15));
+    ++n_done;
+#endif
+  };
+
   // This wave's blocks.  With 8 waves the second wave of each SIMD gets its first requests out several
   // thousand cycles after the first (the CU's memory path takes a workgroup's cold first round at a
   // fraction of its steady rate) and would finish that much later; so the first four waves take a head
@@ -276,31 +359,76 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   auto next = [&](int kb) { return (HEAD && kb - kb_lo < 8) ? kb + 4 : kb + KW; };
   int kb = kb_lo + ((HEAD && w >= 4) ? 8 + w : w);
   int nblk = 0;
-  for (int b = kb; b < kb_hi; b = next(b)) ++nblk;
+  if constexpr (HEAD) {
+    for (int b = kb; b < kb_hi; b = next(b)) ++nblk;
+  } else {
+    nblk = kb < kb_hi ? (kb_hi - kb + KW - 1) / KW : 0;
+  }
+  WSet w0, w1;
   if (nblk > 0) {
-    WSet w0, w1;
     load_w(kb, w0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(26);
-    dma_x(kb, 0);
+    const int sl0 = DBL ? (nblk & 1) : 0;  // (two slabs per wave: see the main loop)
+    dma_x(kb, 0, sl0);
     __builtin_amdgcn_sched_barrier(0);  // half 0 before half 1: the counted waits rely on the issue order
     STAMP(27);
-    dma_x(kb, 1);
+    dma_x(kb, 1, sl0);
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(1);
+  }
+  // (everything the first block needs is on its way: now the set-up that needs no memory)
+  {
+    const int f = (r32 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xrd[ks] = wbase + r32 * 128 + (((2 * ks + h) ^ f) << 4);  // row r32 (+ 32 mt), chunk 2 ks + h
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  dqc = make_dq_const();
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  if (nblk > 0) {
     int i = 0;
-    for (; i + 2 < nblk; i += 2) {
-      const int k1 = next(kb), k2 = next(k1);
-      block(Flag<0>{}, k1, w0, w1);
-      block(Flag<0>{}, k2, w1, w0);
-      kb = k2;
+    if constexpr (DBL) {
+      // Blocks alternate between the two slabs at compile time, two per trip; the wave's last block always reads
+      // slab 1 and weight set w0 (one call site: the accumulators never meet from two paths).  So the prologue
+      // fills slab 1 when the number of blocks is odd, and a leading single block brings the rest to an even count.
+      if ((nblk & 1) && nblk > 1) {
+        kb = next(kb);
+        block2(Flag<0>{}, Flag<1>{}, kb, w0, w1);
+        w0 = w1;
+        i = 1;
+      }
+      for (; i + 2 < nblk; i += 2) {
+        const int k1 = next(kb), k2 = next(k1);
+        block2(Flag<0>{}, Flag<0>{}, k1, w0, w1);
+        block2(Flag<0>{}, Flag<1>{}, k2, w1, w0);
+        kb = k2;
+      }
+      if (nblk > 1) {
+        kb = next(kb);
+        block2(Flag<0>{}, Flag<0>{}, kb, w0, w1);
+        w0 = w1;
+      }
+      block2(Flag<1>{}, Flag<1>{}, kb, w0, w1);
+    } else {
+      for (; i + 2 < nblk; i += 2) {
+        const int k1 = next(kb), k2 = next(k1);
+        block(Flag<0>{}, k1, w0, w1);
+        block(Flag<0>{}, k2, w1, w0);
+        kb = k2;
+      }
+      if (i + 1 < nblk) {
+        kb = next(kb);
+        block(Flag<0>{}, kb, w0, w1);
+        w0 = w1;
+      }
+      block(Flag<1>{}, kb, w0, w1);
     }
-    if (i + 1 < nblk) {
-      kb = next(kb);
-      block(Flag<0>{}, kb, w0, w1);
-      w0 = w1;
-    }
-    block(Flag<1>{}, kb, w0, w1);
   }
 
   // Cross-wave reduction through LDS (the slabs are free once every wave is past the first barrier).  A wave's
@@ -464,7 +592,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 
 template <int MT, int T, int KW>
 int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
-  constexpr int stage = KW * MT * 32 * 256;  // one private slab per wave
+  constexpr int stage = KW * MT * 32 * 256 * (wide_double_slab(MT, KW) ? 2 : 1);  // one or two private slabs per wave
   constexpr int per = wide_slices_per_owner(MT, T, true);  // (the larger of the two epilogues' inbox sizes)
   constexpr int inbox = 12 * per * 1024 + 16;               // 4 owners x 3 senders, then the ticket word
   constexpr int park = KW > 4 ? 4 * T * MT * 4 * 1024 : 0;  // 8 waves: the upper four park whole partial tiles first
@@ -472,7 +600,7 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int split
   constexpr int lds = stage > reduce ? stage : reduce;
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks only, and 32-bit byte offsets into the three buffers
-  if (a.K % 128 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31)) return W4A16_E_SHAPE;
+  if (a.K % 128 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K * 2 + kDmaImmBias >= (1LL << 32)) return W4A16_E_SHAPE;
   // fused activation: a tile is 16 gate + 16 up columns, so there are N / 32 of them too
   if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T);

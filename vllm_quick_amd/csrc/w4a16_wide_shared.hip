@@ -73,13 +73,15 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     woff[t] = ((uint32_t)t16 * a.KBS * 64 + ((lane & 15) + 16 * h)) * 16u;
     szoff[t] = ((uint32_t)t16 * a.NG * 16 + (lane & 15)) * 4u;
   }
-  // this wave's pieces of a slab: piece p = w + NW j covers rows 4 p .. 4 p + 3; lane -> row 4 p + (lane >> 4),
-  // 16-byte position lane & 15, which holds chunk (lane & 15) ^ (row & 15) of the row's 128 k
+  // this wave's pieces of a slab: piece p = ND w + j covers rows 4 p .. 4 p + 3; lane -> row 4 p + (lane >> 4),
+  // 16-byte position lane & 15, which holds chunk (lane & 15) ^ (row & 15) of the row's 128 k.  A wave's pieces are
+  // neighbours in LDS: up to four of them share one LDS base (M0) and differ in the instruction's immediate offset,
+  // which moves the LDS address and the source address alike, so the lane offsets are smaller by the same amount.
   uint32_t xoff[ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j) {
-    const int row = 4 * (w + NW * j) + (lane >> 4);
-    xoff[j] = ((uint32_t)min(m0 + row, a.M - 1) * a.K + ((lane & 15) ^ (row & 15)) * 8) * 2u;
+    const int row = 4 * (w * ND + j) + (lane >> 4);
+    xoff[j] = ((uint32_t)min(m0 + row, a.M - 1) * a.K + ((lane & 15) ^ (row & 15)) * 8) * 2u + kDmaImmBias - (uint32_t)(j & 3) * 1024u;
   }
   // B fragment of k-step ks (0..7): row r32 (+ 32 mt), chunk 2 ks + h
   const int xrd = r32 * 256;
@@ -98,20 +100,22 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.pw), 0, (int)((long long)a.NT * a.KBS * 1024), 0x00020000);
   const __amdgpu_buffer_rsrc_t sz_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.psz), 0, a.NT * a.NG * 64, 0x00020000);
-  const __amdgpu_buffer_rsrc_t x_rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(a.x), 0, a.M * a.K * 2, 0x00020000);
+  // (the activations' descriptor starts kDmaImmBias bytes BEFORE the matrix and every lane offset is larger by that
+  // much: a DMA instruction with an immediate offset then takes it off its lane offset without going below zero)
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<unsigned char*>(const_cast<f16*>(a.x)) - kDmaImmBias, 0, (int)((uint32_t)a.M * (uint32_t)a.K * 2u + kDmaImmBias), 0x00020000);
   struct WSet {
     uint32_t sz[T][NSZ];
     u32x4 q[T][2];
   };
   auto load_w = [&](int kb, WSet& b) {
+    int goff[NSZ];  // (once per block, not per tile: the waves of a workgroup share one scalar unit)
+#pragma unroll
+    for (int s = 0; s < NSZ; ++s) goff[s] = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1) * 64;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int s = 0; s < NSZ; ++s) {
-        const int g = min(group_of<SZS>(a, kb * 128 + s * SZS * 32), a.NG - 1);
-        b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], g * 64, 0);
-      }
+      for (int s = 0; s < NSZ; ++s) b.sz[t][s] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[t], goff[s], 0);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       b.q[t][0] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t], kb * 1024, 0);
@@ -122,16 +126,26 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
 #ifdef W4A16_CHECK_DMA
 #pragma unroll
     for (int j = 0; j < ND; ++j)
-      *reinterpret_cast<u32x4*>(smem_raw + buf * SLAB + (w + NW * j) * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
+      *reinterpret_cast<u32x4*>(smem_raw + buf * SLAB + (w * ND + j) * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pattern is in place before the DMA can land on it
 #endif
-#pragma unroll
-    for (int j = 0; j < ND; ++j)
+    auto issue = [&](int j, auto imm_) {  // (the immediate has to be a literal)
+      constexpr int IMM = decltype(imm_)::value;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w + NW * j) * 1024), 16, xoff[j],
-          kb * 256, 0, 0);
+          x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w * ND + (j & ~3)) * 1024), 16,
+          xoff[j], kb * 256, IMM, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      switch (j & 3) {
+        case 0: issue(j, Flag<0>{}); break;
+        case 1: issue(j, Flag<1024>{}); break;
+        case 2: issue(j, Flag<2048>{}); break;
+        default: issue(j, Flag<3072>{}); break;
+      }
+    }
 #ifdef W4A16_CHECK_DMA
-    if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + buf * SLAB + w * 1024 + lane * 16), &g_dma_state[0]);
+    if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + buf * SLAB + w * ND * 1024 + lane * 16), &g_dma_state[0]);
 #endif
   };
   auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
@@ -389,7 +403,7 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   constexpr int lds = ring_slabs<MT, T, NW>() * MT * 32 * 256;  // ring of slabs
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks, at least two of them, and 32-bit byte offsets
-  if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K >= (1LL << 31))
+  if (a.K % 128 || a.K < 256 || (long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.M * a.K * 2 + kDmaImmBias >= (1LL << 32))
     return W4A16_E_SHAPE;
   if (act && a.N % 32) return W4A16_E_SHAPE;
   const int n_slices = ceil_div(ceil_div(a.N, 32), T * NW);
