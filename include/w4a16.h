@@ -204,6 +204,22 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
                              int epilogue, int mt, int t, int a, int b, void* stream);
 
 /*
+ * bf16 activations on the same packed weights: out [M, N] (bf16) = x [M, K] (bf16) @ W (+ bias, bf16), fp32
+ * accumulation, with W = bf16((q - z) * s) rounded once from the exact product (scales as the checkpoint holds
+ * them, fp16).  No counterpart in the reference, whose AWQ path accepts fp16 only
+ * (vllm/model_executor/layers/quantization/awq.py:42-43): there is no reference result to compare with, the tests
+ * check against a float64 restatement of the definition above.  Epilogues: W4A16_EPI_NONE, W4A16_EPI_ADD_TO_OUT
+ * (bf16 + bf16, rounded once); others return W4A16_E_SHAPE.  mt == 0: the library's launch shape; else
+ * (mt, t, waves) of the streaming kernel as built for bf16 (w4a16_built_shape_bf16), W4A16_E_SHAPE otherwise.
+ * One 16x16x32 bf16 matrix-core kernel serves every row count (row blocks of 16 or 32 side by side): sized for
+ * decode-sized batches, correct but not tuned beyond them.
+ */
+int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* packed_sz, const void* bias, void* out,
+                           int M, int K, int N, int G, int epilogue, int mt, int t, int waves, void* stream);
+/* The i-th built (mt, t, waves) of the bf16 kernel in shape[3]; W4A16_E_SHAPE past the end. */
+int w4a16_built_shape_bf16(int i, int* shape);
+
+/*
  * w4a16_gemm_packed_f16_ex with the library's launch shape and a per-problem switch: `problem_mask`
  * is a DEVICE array of `batch` int32 (NULL = all on); problems whose entry is 0 are skipped and their
  * part of `out` is left as it was.  The mask is read by the kernel, not by the host, so it can be the

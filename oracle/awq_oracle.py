@@ -186,6 +186,47 @@ def gemm_exact(x, qweight, scales, qzeros) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
+# bf16 activations: an extension with NO reference counterpart (the reference's AWQ path is fp16 only,
+# vllm/model_executor/layers/quantization/awq.py:42-43): parity unpinned by construction.  What is restated here is
+# the extension's own definition: w = bf16_rne((q - z) * s) with the fp16 scale, one rounding from the exact
+# product; y = sum_k w * x in float64 (the kernel accumulates in fp32 and rounds the sum to bf16 once).
+# bf16 values travel as uint16 bit patterns (numpy has no bf16).
+# --------------------------------------------------------------------------
+def f32_to_bf16_bits(v: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even of float32 values to bf16 bit patterns (finite inputs)."""
+    u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def dequantize_bf16(qweight: np.ndarray, scales: np.ndarray, qzeros: np.ndarray) -> np.ndarray:
+    """bf16 bit patterns [K, N] of bf16_rne((q - z) * s): the product of a 5-bit integer and an 11-bit significand
+    is exact in fp32."""
+    K, N, G = _check(qweight, scales, qzeros, strict_reference=False)
+    q = unpack_words(qweight).astype(np.float32)
+    z = unpack_words(qzeros).astype(np.float32)
+    s = np.asarray(scales, dtype=np.float16).astype(np.float32)
+    d = q.reshape(K // G, G, N) - z[:, None, :]
+    return f32_to_bf16_bits((d * s[:, None, :]).reshape(K, N))
+
+
+def gemm_bf16_exact(x_bits: np.ndarray, qweight, scales, qzeros) -> np.ndarray:
+    """float64 [M, N]: bf16 activations (bit patterns) times the bf16 weights above, float64 accumulation."""
+    w = bf16_bits_to_f32(dequantize_bf16(qweight, scales, qzeros)).astype(np.float64)
+    return bf16_bits_to_f32(x_bits).astype(np.float64) @ w
+
+
+def gemm_bf16_abs(x_bits: np.ndarray, qweight, scales, qzeros) -> np.ndarray:
+    """sum_k |w * x| per output, float64: scales the bound on the kernel's fp32 accumulation error."""
+    w = np.abs(bf16_bits_to_f32(dequantize_bf16(qweight, scales, qzeros)).astype(np.float64))
+    return np.abs(bf16_bits_to_f32(x_bits).astype(np.float64)) @ w
+
+
+# --------------------------------------------------------------------------
 # synthetic inputs (seeded), shared by tests, fixtures and the benchmark
 # --------------------------------------------------------------------------
 def make_inputs(M: int, K: int, N: int, G: int, seed: int = 0, x_scale: float = 0.25):

@@ -33,7 +33,7 @@ def _require(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.dtype != dtype:
-        want = {torch.float16: "Half", torch.int32: "Int"}[dtype]
+        want = {torch.float16: "Half", torch.int32: "Int", torch.bfloat16: "BFloat16"}[dtype]
         raise RuntimeError(f"expected scalar type {want} but found {t.dtype} for {name}")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a GPU tensor: the W4A16 path has no CPU implementation")
@@ -158,6 +158,8 @@ def awq_gemm_packed(in_feats: torch.Tensor,
                     cfg: Optional[Tuple[int, int, int]] = None,
                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[M, K] fp16 @ packed weights (+ bias) -> [M, N] fp16.  `cfg` = (mt, t, waves), (mt, t, nw, kw) for the LDS-staged kernel, ("wide", mt, t, kw) for the 32x32x16 kernel or ("decode", t, waves, splits) for the decode kernel overrides the launch shape.  `workspace` (see `gemm_workspace`) lets the library split K over workgroups where that pays."""
+    if isinstance(in_feats, torch.Tensor) and in_feats.dtype == torch.bfloat16:
+        return awq_gemm_packed_bf16(in_feats, packed, bias, cfg)  # (no workspace: the bf16 kernel splits nothing)
     _require(in_feats, torch.float16, "in_feats")
     if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
         raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
@@ -224,6 +226,48 @@ def awq_gemm_packed(in_feats: torch.Tensor,
                                                packed.packed_sz.data_ptr(), bias_ptr, out.data_ptr(), M, packed.K,
                                                packed.N, packed.G, mt, t, waves, _stream())
         check(rc, "awq_gemm")
+    return out
+
+
+def awq_gemm_packed_bf16(in_feats: torch.Tensor,
+                         packed: PackedAWQ,
+                         bias: Optional[torch.Tensor] = None,
+                         cfg: Optional[Tuple[int, int, int]] = None,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M, K] bf16 @ packed weights (+ bias, bf16) -> [M, N] bf16, with weights bf16((q - z) * s) rounded once and
+    fp32 accumulation.  An extension: the reference's AWQ path takes fp16 only (awq.py:42-43), so nothing in it pins
+    these results; the scales stay fp16 as the checkpoint holds them.  `cfg` = (mt, t, waves) of the streaming kernel
+    as built for bf16; `out` ([M, N] bf16, contiguous): the result is ADDED to it in place (bf16 + bf16, rounded
+    once) and returned."""
+    _require(in_feats, torch.bfloat16, "in_feats")
+    if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:
+        raise ValueError(f"in_feats must be [M, {packed.K}], got {tuple(in_feats.shape)}")
+    if in_feats.device != packed.device:
+        raise RuntimeError("in_feats and the packed weights are on different devices")
+    x = in_feats.contiguous()
+    M = x.shape[0]
+    bias_ptr = None
+    if bias is not None:
+        _require(bias, torch.bfloat16, "bias")
+        if bias.numel() != packed.N:
+            raise ValueError(f"bias must have {packed.N} elements")
+        bias = bias.contiguous()
+        bias_ptr = bias.data_ptr()
+    epilogue = 0
+    if out is not None:
+        _require(out, torch.bfloat16, "out")
+        if tuple(out.shape) != (M, packed.N) or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"out must be a contiguous [{M}, {packed.N}] tensor on the device of in_feats")
+        epilogue = 2  # W4A16_EPI_ADD_TO_OUT
+    mt, t, waves = cfg if cfg is not None else (0, 0, 0)
+    with _on_device(x.device):
+        if out is None:
+            out = torch.empty((M, packed.N), dtype=torch.bfloat16, device=x.device)
+        if M == 0:
+            return out
+        rc = lib.w4a16_gemm_packed_bf16(x.data_ptr(), packed.packed_w.data_ptr(), packed.packed_sz.data_ptr(), bias_ptr,
+                                        out.data_ptr(), M, packed.K, packed.N, packed.G, epilogue, mt, t, waves, _stream())
+        check(rc, "awq_gemm (bf16)")
     return out
 
 
@@ -583,7 +627,9 @@ def awq_gemm(_in_feats: torch.Tensor, _kernel: torch.Tensor, _scaling_factors: t
     satisfy it); OC % 8, G % 32 and IC % G are.
     """
     K, N, G = _geometry(_kernel, _scaling_factors, _zeros)
-    _require(_in_feats, torch.float16, "in_feats")
+    # bf16 activations (an extension; the reference takes fp16 only) run on the packed copy alone
+    bf16 = isinstance(_in_feats, torch.Tensor) and _in_feats.dtype == torch.bfloat16
+    _require(_in_feats, torch.bfloat16 if bf16 else torch.float16, "in_feats")
     if _in_feats.dim() != 2 or _in_feats.shape[1] != K:
         raise ValueError(f"in_feats must be [M, {K}], got {tuple(_in_feats.shape)}")
     if G % 32 != 0:
@@ -595,6 +641,10 @@ def awq_gemm(_in_feats: torch.Tensor, _kernel: torch.Tensor, _scaling_factors: t
         # No packed copy can be made now (non-contiguous tensors, or the stream is being captured and this
         # layer was never called before): the stock-layout kernel serves the call, three to five times slower,
         # and if this is a capture the graph keeps it.  Counted, and said once.
+        if bf16:
+            raise RuntimeError("awq_gemm: bf16 activations need the packed copy of the weights, which cannot be made "
+                               "now (non-contiguous weight tensors, or a first call on these weights while a HIP graph "
+                               "is being captured): run one eager call per layer first")
         global _stock_calls
         _stock_calls += 1
         if _stock_calls == 1:

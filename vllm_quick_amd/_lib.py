@@ -59,6 +59,8 @@ SYMBOLS = {
     "w4a16_launch_shape": (c_int, [c_int] * 5 + [ctypes.POINTER(c_int)]),
     "w4a16_built_shape": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "w4a16_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "w4a16_gemm_packed_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "w4a16_built_shape_bf16": (c_int, [c_int, ctypes.POINTER(c_int)]),
     "w4a16_moe_route_f16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "w4a16_moe_combine_f16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }

@@ -181,8 +181,10 @@ std::shared_ptr<Packed> packed_for(const torch::Tensor& kernel, const torch::Ten
 torch::Tensor awq_gemm(torch::Tensor _in_feats, torch::Tensor _kernel, torch::Tensor _scaling_factors,
                        torch::Tensor _zeros, int split_k_iters) {
   const Geometry g = geometry(_kernel, _scaling_factors, _zeros);
-  TORCH_CHECK(_in_feats.scalar_type() == at::kHalf, "expected scalar type Half but found ", _in_feats.scalar_type(),
-              " for in_feats");
+  // bf16 activations are an extension (the reference takes fp16 only): they run on the packed copy alone
+  const bool bf16 = _in_feats.scalar_type() == at::kBFloat16;
+  TORCH_CHECK(bf16 || _in_feats.scalar_type() == at::kHalf, "expected scalar type Half but found ",
+              _in_feats.scalar_type(), " for in_feats");
   TORCH_CHECK(_in_feats.is_cuda() && _in_feats.device() == _kernel.device(),
               "in_feats must be a GPU tensor on the device of the weights");
   if (_in_feats.dim() != 2 || _in_feats.size(1) != g.K) throw std::invalid_argument("in_feats must be [M, IC]");
@@ -195,12 +197,20 @@ torch::Tensor awq_gemm(torch::Tensor _in_feats, torch::Tensor _kernel, torch::Te
   std::shared_ptr<Packed> packed;
   if (_kernel.is_contiguous() && _scaling_factors.is_contiguous() && _zeros.is_contiguous())
     packed = packed_for(_kernel, _scaling_factors, _zeros, g, stream);
+  if (packed && bf16) {
+    raise_for(w4a16_gemm_packed_bf16(x.data_ptr(), packed->w.data_ptr(), packed->sz.data_ptr(), nullptr,
+                                     out.data_ptr(), M, g.K, g.N, g.G, W4A16_EPI_NONE, 0, 0, 0, stream),
+              "awq_gemm (bf16)");
+    return out;
+  }
   if (packed) {
     raise_for(w4a16_gemm_packed_f16(x.data_ptr(), packed->w.data_ptr(), packed->sz.data_ptr(), nullptr, out.data_ptr(),
                                     M, g.K, g.N, g.G, stream),
               "awq_gemm");
     return out;
   }
+  TORCH_CHECK(!bf16, "awq_gemm: bf16 activations need the packed copy of the weights, which cannot be made now "
+                     "(non-contiguous weights, or a first call on these weights under graph capture)");
   ++g_stock_calls;
   TORCH_WARN_ONCE(
       "awq_gemm: serving a call with the shape-agnostic kernel on the stock layout (non-contiguous weights, or a "

@@ -514,6 +514,52 @@ int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const
                              N, G, batch, W4A16_EPI_NONE, 0, 0, 0, 0, stream);
 }
 
+// bf16 activations: launch shape of the streaming kernel.  One 16-row tile up to 16 rows (16 waves over K where K is
+// long enough to give every wave a block, up to three column tiles per workgroup), two row tiles beyond (8 waves,
+// row blocks of 32 in gridDim.y, as many column tiles per workgroup as still leave a workgroup per CU).
+static void choose_bf16(int M, int K, int N, int* mt, int* t, int* waves) {
+  const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
+  if (M <= 16) {
+    *mt = 1;
+    if (KB >= 16 && NT <= 3 * 256) {
+      *waves = 16;
+      *t = NT <= 256 ? 1 : NT <= 512 ? 2 : 3;
+    } else {
+      *waves = 8;
+      *t = NT <= 2 * 256 ? 2 : 4;
+    }
+    return;
+  }
+  *mt = 2;
+  *waves = 8;
+  const long long per_cu = (long long)NT * ceil_div(M, 32) / 256;
+  *t = per_cu >= 4 ? 4 : per_cu >= 3 ? 3 : per_cu >= 2 ? 2 : 1;
+}
+
+int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* packed_sz, const void* bias, void* out,
+                           int M, int K, int N, int G, int epilogue, int mt, int t, int waves, void* stream) {
+  if (epilogue != W4A16_EPI_NONE && epilogue != W4A16_EPI_ADD_TO_OUT) return W4A16_E_SHAPE;
+  GemmArgs a;
+  const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
+  if (rc) return rc;
+  a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
+  if (mt == 0) choose_bf16(M, K, N, &mt, &t, &waves);
+  clear_stale_error();
+  return dispatch_packed_bf16(a, mt, t, waves, static_cast<hipStream_t>(stream));
+}
+
+int w4a16_built_shape_bf16(int i, int* shape) {
+  if (!shape || i < 0) return W4A16_E_SHAPE;
+  static const int built[][3] = {
+#define X(MT_, T_, W_) {MT_, T_, W_},
+      W4A16_FOR_EACH_BF16(X)
+#undef X
+  };
+  if (i >= (int)(sizeof(built) / sizeof(built[0]))) return W4A16_E_SHAPE;
+  for (int j = 0; j < 3; ++j) shape[j] = built[i][j];
+  return W4A16_OK;
+}
+
 int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void* packed_w,
                              const void* packed_sz, const void* bias, void* out,
                              long long out_batch_stride, int M, int K, int N, int G, int batch,

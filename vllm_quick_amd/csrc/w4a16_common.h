@@ -104,6 +104,81 @@ __device__ __forceinline__ f16x8 dequant_word(uint32_t w, const SZ& c) {
   return dequant_word(w, c, k);
 }
 
+// ---------------------------------------------------------------------------
+// bf16 activations (no counterpart in the reference, whose AWQ path is fp16 only: awq.py:42-43)
+// ---------------------------------------------------------------------------
+// Same packed weights, fp16 scales as the checkpoint holds them.  The weight of the bf16 path is
+//   w = bf16((q - z) * s)    rounded once, to nearest even:
+// q - z is formed exactly in fp16 as in the fp16 path (magic number, packed add / fma), the product with the scale
+// exactly in fp32 (5 bits x 11 bits; v_fma_mix_f32 reads the fp16 half in place), one v_cvt_pk_bf16_f32 per pair.
+// gfx950 has no packed bf16 arithmetic: 21 vector instructions per packed word against 13 for fp16.
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct SZB {
+  float s;    // the scale
+  f16x2 nz1;  // as SZ
+  f16x2 nz2;
+};
+__device__ __forceinline__ SZB expand_szb(uint32_t w) {
+  const f16x2 v = as_h2(w);
+  SZB r;
+  r.s = (float)v.x;
+  r.nz1 = f16x2{v.y, v.y};
+  r.nz2 = r.nz1 + f16x2{(f16)960.0f, (f16)960.0f};
+  return r;
+}
+// {bf16(e.x * s), bf16(e.y * s)}; the -0 addend keeps the sign of a zero product
+__device__ __forceinline__ uint32_t scale_to_bf16x2(f16x2 e, float s) {
+  f32x2 p;
+  asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel_hi:[1,0,0]" : "=v"(p.x) : "v"(e), "v"(s));
+  asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(p.y) : "v"(e), "v"(s));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(p, bf16x2));
+}
+__device__ __forceinline__ bf16x8 dequant_word_bf16(uint32_t w, const SZB& c, const DqConst& k) {
+  const uint32_t t = w >> 8;
+  const f16x2 h0 = as_h2((w & k.lo) | k.magic);
+  const f16x2 h1 = as_h2((w & k.hi) | k.magic);
+  const f16x2 h2 = as_h2((t & k.lo) | k.magic);
+  const f16x2 h3 = as_h2((t & k.hi) | k.magic);
+  const f16x2 e0 = h0 + c.nz1;
+  const f16x2 e1 = h1 * k.sixteenth + c.nz2;
+  const f16x2 e2 = h2 + c.nz1;
+  const f16x2 e3 = h3 * k.sixteenth + c.nz2;
+  const u32x4 r = {scale_to_bf16x2(e0, c.s), scale_to_bf16x2(e1, c.s), scale_to_bf16x2(e2, c.s), scale_to_bf16x2(e3, c.s)};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// What a GEMM kernel needs to know about its activation / output type.
+struct ActF16 {
+  typedef f16 elem;
+  typedef f16x4 x4;
+  typedef f16x8 x8;
+  typedef SZ consts;
+  static __device__ __forceinline__ consts expand(uint32_t w) { return expand_sz(w); }
+  static __device__ __forceinline__ x8 dequant(uint32_t w, const consts& c, const DqConst& k) { return dequant_word(w, c, k); }
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ x4 round(f32x4 v) { return x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w}; }
+  static __device__ __forceinline__ x4 add(x4 a, x4 b) { return a + b; }
+};
+struct ActBf16 {
+  typedef bf16 elem;
+  typedef bf16x4 x4;
+  typedef bf16x8 x8;
+  typedef SZB consts;
+  static __device__ __forceinline__ consts expand(uint32_t w) { return expand_szb(w); }
+  static __device__ __forceinline__ x8 dequant(uint32_t w, const consts& c, const DqConst& k) { return dequant_word_bf16(w, c, k); }
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ x4 round(f32x4 v) { return __builtin_convertvector(v, x4); }
+  // bf16 + bf16: the exact sum rounded once (fp32 holds it unless the exponents are more than 16 apart)
+  static __device__ __forceinline__ x4 add(x4 a, x4 b) {
+    return __builtin_convertvector(__builtin_convertvector(a, f32x4) + __builtin_convertvector(b, f32x4), x4);
+  }
+};
+
 // out = silu(gate) * up on fp16 GEMM results, as the reference's activation kernel computes it
 // (csrc/activation_kernels.cu:9-34): silu in fp32 on the fp16 value, rounded to fp16, then an
 // fp16 multiply.
@@ -114,6 +189,18 @@ __device__ __forceinline__ f16x4 silu_mul(f16x4 g, f16x4 u) {
     const float x = (float)g[i];
     const f16 sg = (f16)(x / (1.0f + expf(-x)));
     r[i] = sg * u[i];
+  }
+  return r;
+}
+
+// The same on bf16 results: silu in fp32 on the bf16 value, rounded to bf16, then a bf16 multiply (rounded once).
+__device__ __forceinline__ bf16x4 silu_mul(bf16x4 g, bf16x4 u) {
+  bf16x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = (float)g[i];
+    const bf16 sg = (bf16)(x / (1.0f + expf(-x)));
+    r[i] = (bf16)((float)sg * (float)u[i]);
   }
   return r;
 }
@@ -407,6 +494,8 @@ inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
   X(2, 1, 16)                                                             \
   X(2, 1, 8)  X(2, 2, 8)  X(2, 3, 8)  X(2, 4, 8)  X(2, 6, 8)              \
   X(2, 1, 4)  X(2, 2, 4)  X(2, 3, 4)
+// (mt, t, waves) of the streaming kernel built for bf16 activations
+#define W4A16_FOR_EACH_BF16(X) X(1, 1, 16) X(1, 2, 16) X(1, 3, 16) X(1, 2, 8) X(1, 4, 8) X(2, 1, 8) X(2, 2, 8) X(2, 3, 8) X(2, 4, 8)
 // (mt, t, nw, kw) of the LDS-staged kernel (the shapes choose_cfg can return; the kernel serves what the 32x32x16
 // kernels do not take: K not a multiple of 128, 24-32 rows of short-K or batched problems)
 #define W4A16_FOR_EACH_TILED(X) \
@@ -503,6 +592,8 @@ constexpr int ring_slabs() { return wide_shared_staggered<MT, T, NW>() ? 4 : (NW
 // One dispatcher per kernel family, each defined in that family's translation unit: launch shape -> instantiation.
 W4A16_HIDDEN int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch = 1,
                                  bool act = false);
+// bf16 activations: the streaming kernel's structure at any row count (row blocks of 16 or 32 in gridDim.y)
+W4A16_HIDDEN int dispatch_packed_bf16(const GemmArgs& a, int mt, int t, int waves, hipStream_t s);
 W4A16_HIDDEN int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1,
                                 bool act = false);
 // `splits` > 1: K split over workgroups through the workspace `ws` (4-wave shapes)

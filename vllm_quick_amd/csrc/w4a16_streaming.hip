@@ -13,8 +13,12 @@ namespace {
 //      2 when G == 64, 1 for any other multiple of 32
 // ACT: the weight is [gate | up] (two halves of N/2 columns, N/2 a multiple of 16); the workgroup
 //      takes T/2 column tiles of each half and stores silu(gate) * up, an [M, N/2] output.
-template <int MT, int T, int W, int SZS, bool ACT = false>
+// AT : the activation / output type (ActF16; ActBf16 for the bf16 entry point)
+template <int MT, int T, int W, int SZS, bool ACT = false, class AT = ActF16>
 __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) {
+  typedef typename AT::elem elem;
+  typedef typename AT::x4 ex4;
+  typedef typename AT::x8 ex8;
   fetch_args_now(ga);
   // a masked-out problem of a batched launch: the whole workgroup leaves before it touches memory
   if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
@@ -50,11 +54,11 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   }
   // Rows past M re-read row M-1: output row m depends on x row m only, and rows >= M
   // are never stored, so no masking is needed.
-  const f16* xp[MT];
+  const elem* xp[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = min(m0 + mt * 16 + n16, a.M - 1);
-    xp[mt] = a.x + (size_t)row * a.K + kq * 8;
+    xp[mt] = reinterpret_cast<const elem*>(a.x) + (size_t)row * a.K + kq * 8;
   }
 
   f32x4 acc[T][MT];
@@ -70,17 +74,17 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   // and two row tiles; more rows go to the kernels that stage activations in LDS.)
   static_assert(MT <= 2, "x fragments of a whole block are held in registers");
   struct Block {
-    f16x8 x[4][MT];
+    ex8 x[4][MT];
     uint32_t sz[T][NSZ];
     u32x4 q[T];
   };
 
   // k-steps past K (K not a multiple of 128) re-read k = 0: the packer fills k >= K with q = z, i.e. exact
   // zero weights.
-  auto load_x = [&](int k, f16x8 (&xf)[MT]) {
+  auto load_x = [&](int k, ex8 (&xf)[MT]) {
     const int ke = (k < a.K) ? k : 0;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f16x8*>(xp[mt] + ke);
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const ex8*>(xp[mt] + ke);
   };
 
   auto load_block = [&](int kb, Block& b) {
@@ -106,14 +110,14 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   auto compute_block = [&](const Block& b) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      SZ ct;
+      typename AT::consts ct;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j % SZS == 0) ct = expand_sz(b.sz[t][j / SZS]);
-        const f16x8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(f16x8, b.q[t]) : dequant_word(b.q[t][j], ct, dqc);
+        if (j % SZS == 0) ct = AT::expand(b.sz[t][j / SZS]);
+        const ex8 af = (W4A16_DBG & 8) ? __builtin_bit_cast(ex8, b.q[t]) : AT::dequant(b.q[t][j], ct, dqc);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b.x[j][mt], acc[t][mt], 0, 0, 0);
+          acc[t][mt] = AT::mfma16(af, b.x[j][mt], acc[t][mt]);
       }
     }
   };
@@ -176,8 +180,8 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
   // `out`), column l & 15 (a row m of `out`).  Values are rounded to fp16 first, then the bias is
   // added in fp16: the value of `out + bias` on an fp16 GEMM result (awq.py:163-164).
   auto finish = [&](f32x4 v, int n_bias) {
-    f16x4 h = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-    if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+    ex4 h = AT::round(v);
+    if (a.bias != nullptr) h = AT::add(h, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n_bias));
     return h;
   };
   // i indexes (t, mt) pairs of the first H tiles; with ACT `vu` is the matching tile of the up half
@@ -189,13 +193,13 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
     if constexpr (ACT) {
       const int NH = a.N / 2;
       if (nt < NTH && m < a.M)
-        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+        *reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
     } else {
       if (nt < a.NT && n < a.N && m < a.M) {
-        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
-        f16x4 h = finish(v, n);
+        ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * a.N + n);
+        ex4 h = finish(v, n);
         // fp16 + fp16, as `residual + linear(x)` on fp16 tensors; one lane owns each element
-        if (a.add_out) h = *dst + h;
+        if (a.add_out) h = AT::add(*dst, h);
         *dst = h;
       }
     }
@@ -228,12 +232,12 @@ __global__ void __launch_bounds__(64 * W) gemm_packed_kernel(const GemmArgs ga) 
       const int nt = nt0 + ti, n = nt * 16 + grp * 4, m = m0 + tok;
       if constexpr (ACT) {
         const int NH = a.N / 2;
-        if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+        if (nt < NTH) *reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
       } else {
         if (nt < a.NT && n < a.N) {
-          f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
-          f16x4 hv = finish(v, n);
-          if (a.add_out) hv = *dst + hv;
+          ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * a.N + n);
+          ex4 hv = finish(v, n);
+          if (a.add_out) hv = AT::add(*dst, hv);
           *dst = hv;
         }
       }
@@ -322,7 +326,39 @@ int launch_packed(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   return launched();
 }
 
+// bf16 activations: plain GEMM (+ bias, + add-to-out), one problem per launch
+template <int MT, int T, int W>
+int launch_packed_bf16(const GemmArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)reduce_lds_tiles(W, T * MT) * 1024;
+  const dim3 grid(ceil_div(a.NT, T), ceil_div(a.M, MT * 16), 1);
+  void (*kern)(const GemmArgs) = nullptr;
+  if (a.G % 128 == 0)
+    kern = gemm_packed_kernel<MT, T, W, 4, false, ActBf16>;
+  else if (a.G == 64)
+    kern = gemm_packed_kernel<MT, T, W, 2, false, ActBf16>;
+  else
+    kern = gemm_packed_kernel<MT, T, W, 1, false, ActBf16>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      w4a16_note_hip_error((int)e);
+      return W4A16_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * W), lds, s, a);
+  return launched();
+}
+
 }  // namespace
+
+int dispatch_packed_bf16(const GemmArgs& a, int mt, int t, int waves, hipStream_t s) {
+#define X(MT_, T_, W_) \
+  if (mt == MT_ && t == T_ && waves == W_) return launch_packed_bf16<MT_, T_, W_>(a, s);
+  W4A16_FOR_EACH_BF16(X)
+#undef X
+  return W4A16_E_SHAPE;
+}
 
 int dispatch_packed(const GemmArgs& a, int mt, int t, int waves, hipStream_t s, int batch,
                     bool act) {
