@@ -123,14 +123,23 @@ def test_gemm_within_rounding_of_float64(L, ops, cuda, M):
 
 
 def test_every_built_shape_and_odd_sizes(L, ops, cuda):
-    """K not a multiple of 128, N not a multiple of 16 per workgroup, every built shape at 5 and 40 rows."""
-    K, N, G = 1056, 328, 32
-    for M in (5, 40):
-        xb, qw, s, qz = make(M, K, N, G, seed=7 + M)
-        packed = ops.awq_repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
-        for cfg in built_shapes(L):
-            y = ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed, cfg=cfg)
-            check_gemm(bits_of(y), xb, qw, s, qz, f"M={M} cfg={cfg}")
+    """K not a multiple of 128 (streaming shapes; the 32x32x16 shapes, listed with a negative first entry, take
+    whole 128-k blocks and refuse it) and K = 1280, N not a multiple of 16 per workgroup, every built shape at 5, 40
+    and 150 rows."""
+    N, G = 328, 32
+    for K in (1056, 1280):
+        for M in (5, 40, 150):
+            xb, qw, s, qz = make(M, K, N, G, seed=7 + M + K)
+            packed = ops.awq_repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
+            for cfg in built_shapes(L):
+                if cfg[0] < 0 and K % 128:
+                    with pytest.raises(ValueError):
+                        ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed, cfg=cfg)
+                    continue
+                y = ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed, cfg=cfg)
+                check_gemm(bits_of(y), xb, qw, s, qz, f"M={M} K={K} cfg={cfg}")
+            y = ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed)  # the library's choice
+            check_gemm(bits_of(y), xb, qw, s, qz, f"M={M} K={K} default")
 
 
 def test_bias_and_add_to_out(L, ops, cuda):

@@ -543,8 +543,21 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
   const int rc = fill_args(&a, x, packed_w, packed_sz, bias, out, M, K, N, G);
   if (rc) return rc;
   a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
-  if (mt == 0) choose_bf16(M, K, N, &mt, &t, &waves);
   clear_stale_error();
+  if (mt == 0) {
+    // From 17 rows the 32x32x16 kernel with private slabs (whole 128-k blocks only): one 32-row tile up to 47 rows,
+    // two beyond.
+    const bool wide_ok = K % 128 == 0 && (long long)a.NT * a.KBS * 1024 < (1LL << 32) &&
+                         (long long)M * K * 2 + kDmaImmBias < (1LL << 32);
+    if (M > 16 && wide_ok) {
+      const bool two = M >= 48;
+      return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
+                           nullptr, 0, true);
+    }
+    choose_bf16(M, K, N, &mt, &t, &waves);
+  }
+  if (mt < 0)  // (-mt, t, waves as kw): the 32x32x16 kernel, as w4a16_gemm_packed_f16_wide_cfg names its shapes
+    return dispatch_wide(a, -mt, t, waves, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, true);
   return dispatch_packed_bf16(a, mt, t, waves, static_cast<hipStream_t>(stream));
 }
 
@@ -554,6 +567,7 @@ int w4a16_built_shape_bf16(int i, int* shape) {
 #define X(MT_, T_, W_) {MT_, T_, W_},
       W4A16_FOR_EACH_BF16(X)
 #undef X
+      {-2, 3, 4}, {-1, 2, 8},  // the 32x32x16 kernel (wide_bf16_built)
   };
   if (i >= (int)(sizeof(built) / sizeof(built[0]))) return W4A16_E_SHAPE;
   for (int j = 0; j < 3; ++j) shape[j] = built[i][j];

@@ -161,6 +161,7 @@ struct ActF16 {
   static __device__ __forceinline__ consts expand(uint32_t w) { return expand_sz(w); }
   static __device__ __forceinline__ x8 dequant(uint32_t w, const consts& c, const DqConst& k) { return dequant_word(w, c, k); }
   static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ x4 round(f32x4 v) { return x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w}; }
   static __device__ __forceinline__ x4 add(x4 a, x4 b) { return a + b; }
 };
@@ -172,6 +173,7 @@ struct ActBf16 {
   static __device__ __forceinline__ consts expand(uint32_t w) { return expand_szb(w); }
   static __device__ __forceinline__ x8 dequant(uint32_t w, const consts& c, const DqConst& k) { return dequant_word_bf16(w, c, k); }
   static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ x4 round(f32x4 v) { return __builtin_convertvector(v, x4); }
   // bf16 + bf16: the exact sum rounded once (fp32 holds it unless the exponents are more than 16 apart)
   static __device__ __forceinline__ x4 add(x4 a, x4 b) {
@@ -514,6 +516,8 @@ inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
 #define W4A16_WIDE_DBL 1
 #endif
 constexpr bool wide_double_slab(int mt, int kw) { return W4A16_WIDE_DBL && mt == 2 && kw == 4; }
+// private-slab shapes also built for bf16 activations (17 rows and more)
+constexpr bool wide_bf16_built(int mt, int t, int kw) { return (mt == 2 && t == 3 && kw == 4) || (mt == 1 && t == 2 && kw == 8); }
 constexpr int wide_slices_per_owner(int mt, int t, bool act) { return act ? ((t * mt + 1) / 2) * 2 : t * mt; }
 inline size_t wide_ws_bytes(long long tiles, int splits, int mt, int t, bool act);
 // (mt, t, nw) of the shared-slab 32x32x16 kernel
@@ -597,8 +601,10 @@ W4A16_HIDDEN int dispatch_packed_bf16(const GemmArgs& a, int mt, int t, int wave
 W4A16_HIDDEN int dispatch_tiled(const GemmArgs& a, int mt, int t, int nw, int kw, hipStream_t s, int batch = 1,
                                 bool act = false);
 // `splits` > 1: K split over workgroups through the workspace `ws` (4-wave shapes)
+// `bf16`: bf16 activations (the shapes of wide_bf16_built, one problem, no fused activation, no split)
 W4A16_HIDDEN int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch = 1,
-                               bool act = false, int splits = 1, void* ws = nullptr, size_t ws_bytes = 0);
+                               bool act = false, int splits = 1, void* ws = nullptr, size_t ws_bytes = 0,
+                               bool bf16 = false);
 W4A16_HIDDEN int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1,
                                       bool act = false);
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)

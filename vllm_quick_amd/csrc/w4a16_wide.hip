@@ -33,10 +33,15 @@ namespace {
 // half's k-steps to arrive.  No other wave touches that LDS, so the main loop has no barrier; the
 // DMA's completion is awaited with counted s_waitcnt vmcnt (vector-memory operations of a wave complete
 // in issue order; the compiler does not track data that arrives in LDS this way).
-template <int MT, int T, int KW, int SZS, bool ACT = false>
+// AT: the activation / output type (ActF16; ActBf16 for the bf16 entry point)
+template <int MT, int T, int KW, int SZS, bool ACT = false, class AT = ActF16>
 __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_blocks, int panel_rows,
                                                             const GemmArgs ga, const WideSplit sp) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  typedef typename AT::elem elem;
+  typedef typename AT::x4 ex4;
+  typedef typename AT::x8 ex8;
+  typedef typename AT::consts SZc;
   fetch_args_now(ga);
   asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows), "s"(sp.ws), "s"(sp.tickets), "s"(sp.kb_per_split));
   if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
@@ -176,11 +181,11 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
     for (int p = 0; p < XL; ++p) dma_piece(kb, hp, p, sl);  // (ablation 1: XL is 1, an eighth of the activation traffic)
   };
   // B fragments of k-step `kstep` (0..7) of the block: 2 ds_read_b128 from half kstep / 4
-  auto read_x = [&](int kstep, f16x8 (&xf)[MT], int sl = 0) {
+  auto read_x = [&](int kstep, ex8 (&xf)[MT], int sl = 0) {
     const int hp = kstep >> 2, ks = kstep & 3;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[ks] + sl * SLAB + hp * HALF + mt * 4096);
+      xf[mt] = *reinterpret_cast<const ex8*>(smem_raw + xrd[ks] + sl * SLAB + hp * HALF + mt * 4096);
 #ifdef W4A16_CHECK_DMA
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -188,18 +193,18 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 #endif
   };
   // The weight fragment of tile t at k-step `kstep` (scale/zero constants refreshed where a new group starts)
-  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
-    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
-    if (W4A16_DBG & 4) return __builtin_bit_cast(f16x8, b.q[t][kstep & 1]);  // ablation: no conversion
-    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+  auto convert = [&](int kstep, int t, const WSet& b, SZc (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = AT::expand(b.sz[t][kstep / (2 * SZS)]);
+    if (W4A16_DBG & 4) return __builtin_bit_cast(ex8, b.q[t][kstep & 1]);  // ablation: no conversion
+    return AT::dequant(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
   };
   // One k-step: MT x T matrix instructions.  The conversion runs ONE TILE AHEAD of them (`af0` comes in
   // converted; tiles 1.. and tile 0 of the next k-step are converted here), and the two instruction kinds
   // are dealt out alternately: a wave issues in order, so a matrix instruction that finds the pipe still
   // busy with its predecessor would otherwise hold back the ~52 cycles of conversion behind it, and a
   // single wave would run at half the matrix rate.
-  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
-    f16x8 af[T + 1];
+  auto math = [&](int kstep, const WSet& b, SZc (&c)[T], const ex8 (&xf)[MT], ex8& af0) {
+    ex8 af[T + 1];
     af[0] = af0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -209,7 +214,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
         af[T] = convert(kstep + 1, 0, b, c);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+        acc[t][mt] = AT::mfma32(af[t], xf[mt], acc[t][mt]);
     }
     if (kstep + 1 < 8) af0 = af[T];
     {
@@ -234,15 +239,15 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   // workgroup.)
   auto block = [&](auto last_, int kb_next, const WSet& cur, WSet& nxt) {
     constexpr bool LAST = decltype(last_)::value != 0;
-    SZ c[T];
-    f16x8 xa[MT], xb[MT];
+    SZc c[T];
+    ex8 xa[MT], xb[MT];
     if constexpr (!LAST) {
       load_w(kb_next, nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
     W4A16_DMA_WAIT(LAST ? XL : XL + WL);
     read_x(0, xa);
-    f16x8 af0 = convert(0, 0, cur, c);
+    ex8 af0 = convert(0, 0, cur, c);
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2 += 2) {
       // even k-step on xa while xb arrives, odd k-step on xb while xa arrives
@@ -270,18 +275,18 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   // One k-step for block2: the same arithmetic tile by tile, each tile's matrix instructions and the next tile's
   // conversion in a scheduling region of their own, and `between(t)` (a DMA piece) issued in program order behind
   // tile t's region: right after a matrix instruction has started, so the piece goes out in its shadow.
-  auto math2 = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0, auto&& between) {
-    f16x8 af = af0;
+  auto math2 = [&](int kstep, const WSet& b, SZc (&c)[T], const ex8 (&xf)[MT], ex8& af0, auto&& between) {
+    ex8 af = af0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      f16x8 nx = af;
+      ex8 nx = af;
       if (t + 1 < T)
         nx = convert(kstep, t + 1, b, c);
       else if (kstep + 1 < 8)
         nx = convert(kstep + 1, 0, b, c);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+        acc[t][mt] = AT::mfma32(af, xf[mt], acc[t][mt]);
       constexpr int per = (13 + MT - 1) / MT;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {  // (the matrix instruction last: `between` then goes out in its shadow)
@@ -308,15 +313,15 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   auto block2 = [&](auto last_, auto sl_, int kb_next, const WSet& cur, WSet& nxt) {
     constexpr bool LAST = decltype(last_)::value != 0;
     constexpr int SL = decltype(sl_)::value;
-    SZ c[T];
-    f16x8 xa[MT], xb[MT];
+    SZc c[T];
+    ex8 xa[MT], xb[MT];
     if constexpr (!LAST) {
       load_w(kb_next, nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
     W4A16_DMA_WAIT(LAST ? XLR : XLR + WL);
     read_x(0, xa, SL);
-    f16x8 af0 = convert(0, 0, cur, c);
+    ex8 af0 = convert(0, 0, cur, c);
     // piece j (0 .. MT - 1) of k-step `kstep`: pieces 0 .. XLR - 1 fill half 0, the rest half 1
     auto piece = [&](int kstep, int j) {
       if constexpr (!LAST) {
@@ -561,13 +566,13 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       const int n = (ct0 + t) * 16 + 8 * q + 4 * h;
       if (m < a.M && n < NH) {
         const f32x4 v = fin[j], vu = fin[j + 1];
-        f16x4 hg = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-        f16x4 hu = f16x4{(f16)vu.x, (f16)vu.y, (f16)vu.z, (f16)vu.w};
+        ex4 hg = AT::round(v);
+        ex4 hu = AT::round(vu);
         if (a.bias != nullptr) {
-          hg += *reinterpret_cast<const f16x4*>(a.bias + n);
-          hu += *reinterpret_cast<const f16x4*>(a.bias + NH + n);
+          hg = AT::add(hg, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n));
+          hu = AT::add(hu, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + NH + n));
         }
-        *reinterpret_cast<f16x4*>(a.out + (size_t)m * NH + n) = silu_mul(hg, hu);
+        *reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * NH + n) = silu_mul(hg, hu);
       }
     } else {
       const int t = j / MT, mt = j % MT, q = w;
@@ -575,10 +580,10 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       const int n = (ct0 + t) * 32 + 8 * q + 4 * h;
       if (m < a.M && n < a.N) {
         const f32x4 v = fin[j];
-        f16x4 hv = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-        if (a.bias != nullptr) hv += *reinterpret_cast<const f16x4*>(a.bias + n);
-        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)m * a.N + n);
-        if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+        ex4 hv = AT::round(v);
+        if (a.bias != nullptr) hv = AT::add(hv, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n));
+        ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * a.N + n);
+        if (a.add_out) hv = AT::add(*dst, hv);  // fp16 + fp16 (bf16 + bf16); one lane owns each element
         *dst = hv;
       }
     }
@@ -591,7 +596,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
 }
 
 template <int MT, int T, int KW>
-int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
+int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes, bool bf16 = false) {
   constexpr int stage = KW * MT * 32 * 256 * (wide_double_slab(MT, KW) ? 2 : 1);  // one or two private slabs per wave
   constexpr int per = wide_slices_per_owner(MT, T, true);  // (the larger of the two epilogues' inbox sizes)
   constexpr int inbox = 12 * per * 1024 + 16;               // 4 owners x 3 senders, then the ticket word
@@ -626,7 +631,20 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int split
     sp.ws_bytes = (int)(need - kTicketBytes);
   }
   void (*kern)(int, int, int, const GemmArgs, const WideSplit) = nullptr;
-  if (act) {
+  if (bf16) {
+    // bf16 activations: built for a few shapes, plain GEMM (+ bias, + add-to-out)
+    if constexpr (wide_bf16_built(MT, T, KW)) {
+      if (act || splits > 1 || batch != 1) return W4A16_E_SHAPE;
+      if (a.G % 128 == 0)
+        kern = gemm_wide_kernel<MT, T, KW, 4, false, ActBf16>;
+      else if (a.G == 64)
+        kern = gemm_wide_kernel<MT, T, KW, 2, false, ActBf16>;
+      else
+        kern = gemm_wide_kernel<MT, T, KW, 1, false, ActBf16>;
+    } else {
+      return W4A16_E_SHAPE;
+    }
+  } else if (act) {
     if (a.G % 128 == 0)
       kern = gemm_wide_kernel<MT, T, KW, 4, true>;
     else if (a.G == 64)
@@ -657,9 +675,9 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int split
 }  // namespace
 
 int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStream_t s, int batch, bool act, int splits, void* ws,
-                  size_t ws_bytes) {
+                  size_t ws_bytes, bool bf16) {
 #define X(MT_, T_, KW_) \
-  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch, act, splits, ws, ws_bytes);
+  if (mt == MT_ && t == T_ && kw == KW_) return launch_wide<MT_, T_, KW_>(a, s, batch, act, splits, ws, ws_bytes, bf16);
   W4A16_FOR_EACH_WIDE(X)
 #undef X
   return W4A16_E_SHAPE;
