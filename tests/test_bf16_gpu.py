@@ -45,6 +45,15 @@ def built_shapes(L):
     return out
 
 
+DECODE_TAG = -16  # first entry of a built shape that names the decode kernel (up to 16 rows, whole 128-k blocks)
+
+
+def refused(cfg, M, K):
+    """Launch shapes that do not take the problem: the 32x32x16 and decode kernels want whole 128-k blocks, the decode
+    kernel up to 16 rows."""
+    return cfg is not None and cfg[0] < 0 and (K % 128 != 0 or (cfg[0] == DECODE_TAG and M > 16))
+
+
 def bf16_tensor(bits, cuda):
     return dev_t(bits.view(np.int16), cuda).view(torch.bfloat16)
 
@@ -104,6 +113,8 @@ def test_weights_bit_exact_through_unit_rows(L, ops, cuda, G):
         xb[np.arange(M), rows] = 0x3F80  # 1.0
         tx = bf16_tensor(xb, cuda)
         for cfg in [None] + built_shapes(L):
+            if refused(cfg, M, K):
+                continue
             y = ops.awq_gemm_packed_bf16(tx, packed, cfg=cfg)
             assert y.dtype == torch.bfloat16 and tuple(y.shape) == (M, N)
             got = bits_of(y)
@@ -123,16 +134,16 @@ def test_gemm_within_rounding_of_float64(L, ops, cuda, M):
 
 
 def test_every_built_shape_and_odd_sizes(L, ops, cuda):
-    """K not a multiple of 128 (streaming shapes; the 32x32x16 shapes, listed with a negative first entry, take
-    whole 128-k blocks and refuse it) and K = 1280, N not a multiple of 16 per workgroup, every built shape at 5, 40
-    and 150 rows."""
+    """K not a multiple of 128 (streaming shapes; the 32x32x16 and decode shapes, listed with a negative first entry,
+    take whole 128-k blocks and refuse it, the decode shapes also more than 16 rows) and K = 1280, N not a multiple of
+    16 per workgroup, every built shape at 5, 16, 40 and 150 rows."""
     N, G = 328, 32
     for K in (1056, 1280):
-        for M in (5, 40, 150):
+        for M in (5, 16, 40, 150):
             xb, qw, s, qz = make(M, K, N, G, seed=7 + M + K)
             packed = ops.awq_repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
             for cfg in built_shapes(L):
-                if cfg[0] < 0 and K % 128:
+                if refused(cfg, M, K):
                     with pytest.raises(ValueError):
                         ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed, cfg=cfg)
                     continue

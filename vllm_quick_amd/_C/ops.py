@@ -236,8 +236,9 @@ def awq_gemm_packed_bf16(in_feats: torch.Tensor,
                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[M, K] bf16 @ packed weights (+ bias, bf16) -> [M, N] bf16, with weights bf16((q - z) * s) rounded once and
     fp32 accumulation.  An extension: the reference's AWQ path takes fp16 only (awq.py:42-43), so nothing in it pins
-    these results; the scales stay fp16 as the checkpoint holds them.  `cfg` = (mt, t, waves) of the streaming kernel
-    as built for bf16; `out` ([M, N] bf16, contiguous): the result is ADDED to it in place (bf16 + bf16, rounded
+    these results; the scales stay fp16 as the checkpoint holds them.  `cfg` = a launch shape as
+    `w4a16_built_shape_bf16` lists them: (mt, t, waves) of the streaming kernel, (-16, t, waves) of the decode kernel
+    (up to 16 rows), (-mt, t, kw) of the 32x32x16 kernel; `out` ([M, N] bf16, contiguous): the result is ADDED to it in place (bf16 + bf16, rounded
     once) and returned."""
     _require(in_feats, torch.bfloat16, "in_feats")
     if in_feats.dim() != 2 or in_feats.shape[1] != packed.K:

@@ -519,6 +519,7 @@ int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const
 // bf16 activations: launch shape of the streaming kernel.  One 16-row tile up to 16 rows (16 waves over K where K is
 // long enough to give every wave a block, up to three column tiles per workgroup), two row tiles beyond (8 waves,
 // row blocks of 32 in gridDim.y, as many column tiles per workgroup as still leave a workgroup per CU).
+constexpr int kBf16DecodeTag = -16;  // first entry of a bf16 launch shape that names the decode kernel
 static void choose_bf16(int M, int K, int N, int* mt, int* t, int* waves) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   if (M <= 16) {
@@ -556,10 +557,19 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
       return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
                            nullptr, 0, true);
     }
+    // Up to 16 rows the decode kernel in the launch shape it takes for fp16 (no K split: no workspace here).
+    if (M <= kDecodeMaxRowsL2) {
+      const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
+      if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
+    }
     choose_bf16(M, K, N, &mt, &t, &waves);
   }
-  if (mt < 0)  // (-mt, t, waves as kw): the 32x32x16 kernel, as w4a16_gemm_packed_f16_wide_cfg names its shapes
+  if (mt < 0) {
+    if (mt == kBf16DecodeTag)  // (tag, t, waves): the decode kernel, up to 16 rows
+      return dispatch_decode(a, t, waves, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
+    // (-mt, t, waves as kw): the 32x32x16 kernel, as w4a16_gemm_packed_f16_wide_cfg names its shapes
     return dispatch_wide(a, -mt, t, waves, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, true);
+  }
   return dispatch_packed_bf16(a, mt, t, waves, static_cast<hipStream_t>(stream));
 }
 
@@ -570,6 +580,9 @@ int w4a16_built_shape_bf16(int i, int* shape) {
       W4A16_FOR_EACH_BF16(X)
 #undef X
       {-2, 3, 4}, {-1, 2, 8},  // the 32x32x16 kernel (wide_bf16_built)
+#define X(T_, W_) {kBf16DecodeTag, T_, W_},
+      W4A16_FOR_EACH_DECODE(X)  // the decode kernel
+#undef X
   };
   if (i >= (int)(sizeof(built) / sizeof(built[0]))) return W4A16_E_SHAPE;
   for (int j = 0; j < 3; ++j) shape[j] = built[i][j];

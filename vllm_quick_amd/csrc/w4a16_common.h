@@ -609,6 +609,6 @@ W4A16_HIDDEN int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, 
                                       bool act = false);
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 W4A16_HIDDEN int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits,
-                                 void* ws, size_t ws_bytes, int depth = 0);
+                                 void* ws, size_t ws_bytes, int depth = 0, bool bf16 = false);
 
 }  // namespace w4a16

@@ -29,9 +29,14 @@ namespace {
 // XLDS = false serves 5-16 rows: the activations then come as B fragments straight from L2, one block ahead of
 // the block being worked on (at 16 rows a fragment load has no lane to spare, and 16 rows x 256 bytes per block
 // and wave would not fit LDS), the waves park whole 16 x 16 partial tiles, and waves 0..H-1 each sum one tile.
-template <int T, int W, int DB, int SZS, bool ACT = false, bool XLDS = true>
+// AT: the activation / output type (fp16 or bf16; the weights of the bf16 path are bf16((q - z) * s), see
+// dequant_word_bf16).
+template <int T, int W, int DB, int SZS, bool ACT = false, bool XLDS = true, class AT = ActF16>
 __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  typedef typename AT::elem elem;
+  typedef typename AT::x4 ex4;
+  typedef typename AT::x8 ex8;
   fetch_args_now(ga);
   asm volatile("" ::"s"(e.ws), "s"(e.tickets), "s"(e.kb_per_split), "s"(e.nb_max), "s"(e.wstride), "s"(e.sstride),
                "s"(e.steal), "s"(e.splits), "s"(e.gx));
@@ -127,34 +132,34 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     }
     d.q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wlane, wbase[t] + kb * 1024, 2));  // nt
   };
-  auto compute_unit = [&](int t, const Unit& d, const f16x8 (&xf)[4]) {
-    SZ c;
+  auto compute_unit = [&](int t, const Unit& d, const ex8 (&xf)[4]) {
+    typename AT::consts c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (j % SZS == 0) c = expand_sz(d.sz[j / SZS]);
-      const f16x8 af = dequant_word(d.q[j], c, dqc);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, xf[j], acc[t], 0, 0, 0);
+      if (j % SZS == 0) c = AT::expand(d.sz[j / SZS]);
+      const ex8 af = AT::dequant(d.q[j], c, dqc);
+      acc[t] = AT::mfma16(af, xf[j], acc[t]);
     }
   };
   // Without LDS staging: the B fragments of a block (row min(n16, M - 1), k = 32 j + 8 kq .. + 7), 4 loads
   const uint32_t xfrag_lane = ((uint32_t)min(n16, a.M - 1) * a.K + kq * 8) * 2u;
-  auto load_x = [&](int kb, f16x8 (&xf)[4]) {
+  auto load_x = [&](int kb, ex8 (&xf)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      xf[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, xfrag_lane, (kb * 128 + j * 32) * 2, 0));
+      xf[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, xfrag_lane, (kb * 128 + j * 32) * 2, 0));
   };
   // One block from the registers `u`; with REFILL each unit's registers are asked to fetch the same tile's unit
   // of block kb_refill as soon as the unit is consumed; with XNEXT (fragments from L2 only) the next block's
   // fragments are requested into `xnext` first.  (Compile-time flags: a load under a run-time branch makes the
   // compiler wait for every load in flight.)
-  auto step = [&](auto refill_, auto xnext_, int bi, Unit (&u)[T], f16x8 (&xcur)[4], f16x8 (&xnext)[4], int kb_refill,
+  auto step = [&](auto refill_, auto xnext_, int bi, Unit (&u)[T], ex8 (&xcur)[4], ex8 (&xnext)[4], int kb_refill,
                   int kb_xnext) {
     constexpr bool REFILL = decltype(refill_)::value != 0;
     constexpr bool XNEXT = decltype(xnext_)::value != 0;
-    f16x8 xl[4];
+    ex8 xl[4];
     if constexpr (XLDS) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem_raw + xrd[j] + bi * 1024);
+      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + bi * 1024);
     } else if constexpr (XNEXT) {
       load_x(kb_xnext, xnext);
       __builtin_amdgcn_sched_barrier(0);
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   };
 
   if (nblk > 0) {
-    f16x8 xa[4], xb[4];
+    ex8 xa[4], xb[4];
     if constexpr (XLDS) {
       // activations first: they come from L2 and are back before the weights
       for (int bi = 0; bi < nblk; ++bi)
@@ -259,20 +264,20 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       for (int s = 1; s < W; ++s) vu += red[(s * T + ti + H) * 64 + lane];
     }
     auto finish = [&](f32x4 r, int n_bias) {
-      f16x4 h = f16x4{(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w};
-      if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+      ex4 h = AT::round(r);
+      if (a.bias != nullptr) h = AT::add(h, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n_bias));
       return h;
     };
     const int nt = nt0 + ti, n = nt * 16 + kq * 4, tok = n16;
     if (tok >= a.M) return;
     if constexpr (ACT) {
       const int NH = a.N / 2;
-      if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+      if (nt < NTH) *reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
     } else {
       if (nt < a.NT && n < a.N) {
-        f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)tok * a.N + n);
-        f16x4 hv = finish(v, n);
-        if (a.add_out) hv = *dst + hv;
+        ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)tok * a.N + n);
+        ex4 hv = finish(v, n);
+        if (a.add_out) hv = AT::add(*dst, hv);
         *dst = hv;
       }
     }
@@ -348,19 +353,19 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   }
   if (!live) continue;
   auto finish = [&](f32x4 r, int n_bias) {
-    f16x4 h = f16x4{(f16)r.x, (f16)r.y, (f16)r.z, (f16)r.w};
-    if (a.bias != nullptr) h += *reinterpret_cast<const f16x4*>(a.bias + n_bias);
+    ex4 h = AT::round(r);
+    if (a.bias != nullptr) h = AT::add(h, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n_bias));
     return h;
   };
   const int nt = nt0 + ti, n = nt * 16 + grp * 4;
   if constexpr (ACT) {
     const int NH = a.N / 2;
-    if (nt < NTH) *reinterpret_cast<f16x4*>(a.out + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
+    if (nt < NTH) *reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)tok * NH + n) = silu_mul(finish(v, n), finish(vu, NH + n));
   } else {
     if (nt < a.NT && n < a.N) {
-      f16x4* dst = reinterpret_cast<f16x4*>(a.out + (size_t)tok * a.N + n);
-      f16x4 hv = finish(v, n);
-      if (a.add_out) hv = *dst + hv;
+      ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)tok * a.N + n);
+      ex4 hv = finish(v, n);
+      if (a.add_out) hv = AT::add(*dst, hv);
       *dst = hv;
     }
   }
@@ -369,10 +374,10 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
 #endif
 }
 
-template <int T, int W, int DB>
+template <int T, int W, int DB, class AT = ActF16>
 int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int splits, void* ws, size_t ws_bytes) {
   constexpr bool kPlain = T <= 8;
-  constexpr bool kAct = T % 2 == 0 && T / 2 <= 8;
+  constexpr bool kAct = T % 2 == 0 && T / 2 <= 8 && std::is_same<AT, ActF16>::value;  // (the fused activation: fp16 only)
   if (!decode_ok(a) || (act && a.N % 32)) return W4A16_E_SHAPE;
   if (act ? !kAct : !kPlain) return W4A16_E_SHAPE;  // (before any division by tiles per workgroup: T / 2 is 0 for T = 1)
   if (splits < 1 || splits > kMaxSplits) return W4A16_E_SHAPE;
@@ -408,11 +413,11 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 #define W4A16_PICK(SZS_)                                                                         \
   if (szs == SZS_) {                                                                             \
     if (act) {                                                                                   \
-      if constexpr (kAct) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, true, true>           \
-                                      : gemm_decode_kernel<T, W, DB, SZS_, true, false>;         \
+      if constexpr (kAct) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, true, true, AT>       \
+                                      : gemm_decode_kernel<T, W, DB, SZS_, true, false, AT>;     \
     } else {                                                                                     \
-      if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, true>        \
-                                        : gemm_decode_kernel<T, W, DB, SZS_, false, false>;      \
+      if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, true, AT>    \
+                                        : gemm_decode_kernel<T, W, DB, SZS_, false, false, AT>;  \
     }                                                                                            \
   }
   W4A16_PICK(4) W4A16_PICK(2) W4A16_PICK(1)
@@ -435,7 +440,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits, void* ws,
-                    size_t ws_bytes, int depth) {
+                    size_t ws_bytes, int depth, bool bf16) {
   // Two blocks per wave in flight where one would leave the CU short of outstanding requests (8192 x 1280 at
   // 1 row 5.2 us against 5.8 with one block, 11008 x 4096 7.0 against 7.9, 8192 x 3584 5.6 against 6.9), but no
   // more than a CU takes in at a time, ~64 KiB (beyond it the youngest waves' first requests wait for the oldest
@@ -453,6 +458,15 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
     // 4 tiles x 4 waves (several workgroups to a CU): one block up to K = 6144 (4096 x 28672 at 1 row 14.0 us
     // against 14.9), two beyond (8 x 14336 x 4096: 46.6 against 52.2)
     if (t == 4 && waves == 4 && a.K < 6144) depth = 1;
+  }
+  if (bf16) {
+#define X(T_, W_)                                                                                     \
+  if (t == T_ && waves == W_)                                                                         \
+    return depth == 1 ? launch_decode<T_, W_, 1, ActBf16>(a, s, batch, act, splits, ws, ws_bytes)     \
+                      : launch_decode<T_, W_, 2, ActBf16>(a, s, batch, act, splits, ws, ws_bytes);
+    W4A16_FOR_EACH_DECODE(X)
+#undef X
+    return W4A16_E_SHAPE;
   }
 #define X(T_, W_)                                                                                     \
   if (t == T_ && waves == W_)                                                                         \
