@@ -458,6 +458,69 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   STAMP(20);
   __syncthreads();
   STAMP(21);
+  // 8 waves whose slices divide evenly among them (and whose 8 x 7 inboxes fit): one exchange among all eight, every
+  // wave owns NSL / 8 slices (slice i belongs to wave i & 7), sums the eight partial results in wave order and stores
+  // them.  One barrier and 7 slices each way per owned slice, where parking and the four-owner exchange take three
+  // barriers and twice the LDS traffic on the critical path.
+  #ifndef W4A16_DIRECT8
+#define W4A16_DIRECT8 1
+#endif
+  constexpr bool DIRECT8 = W4A16_DIRECT8 && KW == 8 && !ACT && NSL % 8 == 0 && 56 * (NSL / 8) <= 160;
+  if constexpr (DIRECT8) {
+    constexpr int P8 = NSL / 8;
+    f32x4 fin8[P8];
+    auto exchange8 = [&](auto me_) {
+      constexpr int ME = decltype(me_)::value;
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) {
+        const int o = i & 7;
+        if (o != ME) red[((o * 7 + ((ME - o - 1) & 7)) * P8 + (i >> 3)) * 64 + lane] = part(i);
+      }
+      __syncthreads();
+      STAMP(22);
+      // inbox f of owner ME holds the copy of wave (ME + 1 + f) & 7: all reads first, then the sums in wave order
+      f32x4 got[P8][7];
+#pragma unroll
+      for (int j = 0; j < P8; ++j)
+#pragma unroll
+        for (int f = 0; f < 7; ++f) got[j][f] = red[((ME * 7 + f) * P8 + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < P8; ++j) {
+        fin8[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int src = 0; src < 8; ++src) fin8[j] += src == ME ? part(8 * j + ME) : got[j][(src - ME - 1) & 7];
+      }
+    };
+    switch (w) {
+      case 0: exchange8(Flag<0>{}); break;
+      case 1: exchange8(Flag<1>{}); break;
+      case 2: exchange8(Flag<2>{}); break;
+      case 3: exchange8(Flag<3>{}); break;
+      case 4: exchange8(Flag<4>{}); break;
+      case 5: exchange8(Flag<5>{}); break;
+      case 6: exchange8(Flag<6>{}); break;
+      default: exchange8(Flag<7>{}); break;
+    }
+#pragma unroll
+    for (int j = 0; j < P8; ++j) {
+      const int tm = 2 * j + (w >> 2), q = w & 3;  // slice 8 j + w = (tile tm, register group q)
+      const int t = tm / MT, mt = tm % MT;
+      const int m = m0 + mt * 32 + r32;
+      const int n = (ct0 + t) * 32 + 8 * q + 4 * h;
+      if (m < a.M && n < a.N) {
+        ex4 hv = AT::round(fin8[j]);
+        if (a.bias != nullptr) hv = AT::add(hv, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n));
+        ex4* dst = reinterpret_cast<ex4*>(reinterpret_cast<elem*>(a.out) + (size_t)m * a.N + n);
+        if (a.add_out) hv = AT::add(*dst, hv);
+        *dst = hv;
+      }
+    }
+    STAMP(23);
+#ifdef W4A16_STAMPS
+    if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;
+  }
   if constexpr (KW == 8) {
     if (w >= 4) {
 #pragma unroll
@@ -601,7 +664,9 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int split
   constexpr int per = wide_slices_per_owner(MT, T, true);  // (the larger of the two epilogues' inbox sizes)
   constexpr int inbox = 12 * per * 1024 + 16;               // 4 owners x 3 senders, then the ticket word
   constexpr int park = KW > 4 ? 4 * T * MT * 4 * 1024 : 0;  // 8 waves: the upper four park whole partial tiles first
-  constexpr int reduce = park > inbox ? park : inbox;
+  constexpr int direct8 = KW == 8 && (T * MT * 4) % 8 == 0 ? 56 * (T * MT * 4 / 8) * 1024 : 0;  // or: 8 owners x 7 senders
+  constexpr int reduce0 = park > inbox ? park : inbox;
+  constexpr int reduce = direct8 > reduce0 && direct8 <= 160 * 1024 ? direct8 : reduce0;
   constexpr int lds = stage > reduce ? stage : reduce;
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks only, and 32-bit byte offsets into the three buffers

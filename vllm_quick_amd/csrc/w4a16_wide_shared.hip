@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   constexpr int WL = T * (NSZ + 2);         // register loads per weight block and wave
   constexpr int RING = ring_slabs<MT, T, NW>();
   constexpr bool STG = wide_shared_staggered<MT, T, NW>();  // the waves of a SIMD run half a block apart
+#ifndef W4A16_SHARED_SPREAD
+#define W4A16_SHARED_SPREAD 1
+#endif
+  constexpr bool SPREAD = W4A16_SHARED_SPREAD && !STG && RING == 3;  // requests dealt out between the matrix instructions
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int lane = threadIdx.x & 63;
@@ -52,6 +56,12 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   const bool dma_skip_waits = __builtin_amdgcn_readfirstlane(g_dma_state[1]) != 0;
 #endif
 
+#ifdef W4A16_STAMPS
+  constexpr int NWAVES = NW;
+  int n_done = 0;
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
+  STAMP(0);
   int slice, mb;
   if (!map_workgroup(n_slices, m_blocks, panel_rows, a.mb_magic, slice, mb)) return;  // whole workgroup
   // fused activation: a tile is 16 gate columns and the same 16 columns of the up half (as in gemm_wide_kernel)
@@ -148,7 +158,42 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     if (dma_skip_waits) dma_check(*reinterpret_cast<const u32x4*>(smem_raw + buf * SLAB + w * ND * 1024 + lane * 16), &g_dma_state[0]);
 #endif
   };
+  // One of a wave's requests for the next blocks, by index: the WL register loads of weight block `kb_w` (scale/zero
+  // words first), then its ND DMA pieces of block `kb_d`'s slab.  (Indices are constants once the callers' loops are
+  // unrolled; `goff` as in load_w.)
+  auto request = [&](auto lw_, auto dma_, int k, int kb_w, const int (&goff)[NSZ], WSet& b, int kb_d, int buf) {
+    constexpr bool LW = decltype(lw_)::value, DMA = decltype(dma_)::value;
+    if (k < T * NSZ) {
+      if constexpr (LW) b.sz[k / NSZ][k % NSZ] = __builtin_amdgcn_raw_buffer_load_b32(sz_rs, szoff[k / NSZ], goff[k % NSZ], 0);
+    } else if (k < WL) {
+      const int t = (k - T * NSZ) >> 1, hf = (k - T * NSZ) & 1;
+      if constexpr (LW) b.q[t][hf] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] + hf * 512, kb_w * 1024, 0);
+    } else if (k < WL + ND) {
+      if constexpr (DMA) {
+        const int j = k - WL;
+        auto issue = [&](auto imm_) {
+          constexpr int IMM = decltype(imm_)::value;
+#ifdef W4A16_CHECK_DMA
+          *reinterpret_cast<u32x4*>(smem_raw + buf * SLAB + (w * ND + j) * 1024 + lane * 16) = u32x4{kDmaPoison, kDmaPoison, kDmaPoison, kDmaPoison};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              x_rs, (__attribute__((address_space(3))) void*)(smem_raw + buf * SLAB + (w * ND + (j & ~3)) * 1024), 16,
+              xoff[j], kb_d * 256, IMM, 0);
+        };
+        switch (j & 3) {
+          case 0: issue(Flag<0>{}); break;
+          case 1: issue(Flag<1024>{}); break;
+          case 2: issue(Flag<2048>{}); break;
+          default: issue(Flag<3072>{}); break;
+        }
+      }
+    }
+  };
   auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
+#ifdef W4A16_SH_DBG
+    if ((W4A16_SH_DBG & 2) && ks > 0) return;  // ablation: one fragment read per block
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
@@ -160,6 +205,9 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   };
   auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
     if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+#ifdef W4A16_SH_DBG
+    if (W4A16_SH_DBG & 1) return __builtin_bit_cast(f16x8, b.q[t][kstep & 1]);  // ablation: no conversion
+#endif
     return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
   };
   auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
@@ -182,6 +230,34 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
     }
+  };
+  // The same arithmetic tile by tile, each tile's matrix instructions and the next tile's conversion in a scheduling
+  // region of their own, and `between(slot)` (slot = T kstep + t: a request for the next blocks) issued in program
+  // order behind tile t's region, in the shadow of its last matrix instruction.
+  auto math_spread = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0, auto&& between) {
+    f16x8 af = af0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f16x8 nx = af;
+      if (t + 1 < T)
+        nx = convert(kstep, t + 1, b, c);
+      else if (kstep + 1 < 8)
+        nx = convert(kstep + 1, 0, b, c);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+      constexpr int per = (13 + MT - 1) / MT;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      af = nx;
+      __builtin_amdgcn_sched_barrier(0);
+      between(kstep * T + t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    af0 = af;
   };
   // Four k-steps (half HB of a block) from weight set `b`.  On entry `xa` holds the fragments of the half's first
   // k-step and `af0` tile 0's converted weights for it; on exit `af0` holds tile 0's weights of the k-step that
@@ -212,12 +288,51 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   auto block = [&](auto dma, auto lw, int i, const WSet& cur, WSet& nxt) {
     constexpr bool DMA = decltype(dma)::value, LW = decltype(lw)::value;
     const int base = (i % RING) * SLAB + xrd;
+#ifdef W4A16_STAMPS
+    if (n_done < 8) STAMP(2 + 3 * n_done);
+#endif
     // (two slabs: D(i+1) is issued after this barrier, so only W(i) is younger than D(i))
     W4A16_DMA_WAIT((LW && RING == 3) ? ND + WL : WL);
+#ifdef W4A16_STAMPS
+    if (n_done < 8) STAMP(3 + 3 * n_done);
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef W4A16_STAMPS
+    if (n_done < 8) STAMP(4 + 3 * n_done);
+    ++n_done;
+#endif
+    if constexpr (SPREAD) {
+      // The block's requests (W(i + 1), then this wave's pieces of D(i + 2)) go out one or two at a time between the
+      // tiles' matrix instructions instead of in one burst behind the barrier: all waves of the workgroup pass the
+      // barrier together, and the CU's address path takes their NW x (ND + WL) requests at ~16 cycles each while
+      // every wave's in-order issue waits behind its own.  The waits above count a block's requests, not their order.
+      int goff[NSZ];
+#pragma unroll
+      for (int s = 0; s < NSZ; ++s) goff[s] = min(group_of<SZS>(a, (i + 1) * 128 + s * SZS * 32), a.NG - 1) * 64;
+      constexpr int OPS = WL + ND, SLOTS = 8 * T, PER = (OPS + SLOTS - 1) / SLOTS;
+      auto between = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (slot * PER + u < OPS) request(lw, dma, slot * PER + u, i + 1, goff, nxt, i + RING - 1, (i + RING - 1) % RING);
+      };
+      SZ c[T];
+      f16x8 xa[MT], xb[MT];
+      read_x(0, base, xa);
+      f16x8 af0 = convert(0, 0, cur, c);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; k2 += 2) {
+        read_x(k2 + 1, base, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        math_spread(k2, cur, c, xa, af0, between);
+        if (k2 + 2 < 8) read_x(k2 + 2, base, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        math_spread(k2 + 1, cur, c, xb, af0, between);
+      }
+      return;
+    }
     if constexpr (DMA) dma_x(i + RING - 1, (i + RING - 1) % RING);
-    __builtin_amdgcn_sched_barrier(0);  // the wait counts above rely on this issue order: DMA first, then weights
+    __builtin_amdgcn_sched_barrier(0);  // (the waits above count a block's requests, whatever their order)
     if constexpr (LW) load_w(i + 1, nxt);
     __builtin_amdgcn_sched_barrier(0);
     SZ c[T];
@@ -243,6 +358,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   __builtin_amdgcn_sched_barrier(0);
   load_w(0, w0);
   __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
   int i = 0;
   for (; i + 2 <= n - 2; i += 2) {
     block(Flag<1>{}, Flag<1>{}, i, w0, w1);
@@ -361,6 +477,49 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     }
   }
 
+  STAMP(26);
+#ifndef W4A16_SHARED_TSTORE
+#define W4A16_SHARED_TSTORE 1
+#endif
+  if constexpr (!ACT && W4A16_SHARED_TSTORE) {
+    // Stores through a transposing stage in LDS.  In the accumulators a lane holds 4 neighbouring columns of one row
+    // per register group, so a store instruction straight from them writes 32 separate 16-byte pieces (two lanes per
+    // row), and the launch's stores, which all workgroups of a round issue at the same time, are bound by the number
+    // of write requests the L2 channels take, not by bytes.  Each wave instead writes a tile (32 rows x 64 bytes,
+    // 16-byte chunks XOR-swizzled by the row) into 2 KiB of its own in the ring slab that is free by now (slab
+    // KB % RING: no block KB was ever requested, and the last blocks read the other slabs), and reads it back as
+    // 16 rows x 64 bytes per instruction: four lanes per row, 16 bytes each, a quarter of the write requests.
+    // A wave's LDS operations execute in order, so no barrier is needed: the stage is private to the wave.
+    unsigned char* const stage = smem_raw + (n % RING) * SLAB + w * 2048;
+    const int wr = r32 * 64 + 8 * h, wsw = (r32 >> 1) & 3;
+    const int rrow = lane >> 2, rch = lane & 3;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f16x4*>(stage + wr + ((q ^ wsw) << 4)) =
+              f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2], (f16)acc[t][mt][4 * q + 3]};
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = 16 * pass + rrow;
+          f16x8 hv = *reinterpret_cast<const f16x8*>(stage + row * 64 + ((rch ^ ((row >> 1) & 3)) << 4));
+          const int m = m0 + mt * 32 + row, nn = (ct0 + t) * 32 + 8 * rch;
+          if (m < a.M && nn < a.N) {  // (N is a multiple of 8: a chunk is inside or outside as a whole)
+            if (a.bias != nullptr) hv += *reinterpret_cast<const f16x8*>(a.bias + nn);
+            f16x8* dst = reinterpret_cast<f16x8*>(a.out + (size_t)m * a.N + nn);
+            if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
+            *dst = hv;
+          }
+        }
+      }
+    STAMP(27);
+#ifdef W4A16_STAMPS
+    if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;
+  }
   // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -395,6 +554,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
           *dst = hv;
         }
       }
+  STAMP(27);
+#ifdef W4A16_STAMPS
+  if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 
@@ -464,3 +627,5 @@ extern "C" int w4a16_dbg_dma_state_shared(unsigned* host_state, int set_skip) {
   return (int)hipMemcpyFromSymbol(host_state, HIP_SYMBOL(w4a16::g_dma_state), 2 * sizeof(unsigned), 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+W4A16_STAMPS_ACCESSOR
