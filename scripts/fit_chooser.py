@@ -110,7 +110,7 @@ if "--tune" in sys.argv:
             for sh in sorted(c):
                 base = c[sh]
                 best_f, best_l = 1.0, loss(c, records).mean()
-                for f in (0.90, 0.93, 0.96, 0.98, 1.02, 1.04, 1.07, 1.10):
+                for f in (0.80, 0.85, 0.90, 0.93, 0.96, 0.98, 1.02, 1.04, 1.07, 1.10, 1.15, 1.20, 1.25):
                     c[sh] = (base[0] * f, base[1] * f)
                     l_ = loss(c, records).mean()
                     if l_ < best_l - 1e-5:
