@@ -82,6 +82,39 @@ def test_batched_through_c_abi(L, cuda, M, shared):
             assert np.abs(c - b).max() <= 2.0**-10 * max(1.0, np.abs(b).max()), cfg
 
 
+def test_batched_out_stride_of_8_byte_alignment(L, cuda):
+    """Problems whose outputs start 8 bytes (not 16) apart from a 16-byte grid: the out stride only has to be a multiple
+    of 4 elements.  The shared-slab kernel stores 16 bytes per lane, the others 8: both must land where a per-problem
+    launch on the same addresses puts them."""
+    E, M, K, N, G = 3, 70, 384, 208, 128
+    xs, ws = make_problems(E, M, K, N, G, 77, True)
+    lib = L.lib
+    wb, sb = lib.w4a16_packed_weight_bytes(K, N), lib.w4a16_packed_sz_bytes(K, N, G)
+    pw = torch.empty((E, wb), dtype=torch.uint8, device=cuda)
+    ps = torch.empty((E, sb), dtype=torch.uint8, device=cuda)
+    stream = torch.cuda.current_stream().cuda_stream
+    for e, (qw, s, qz) in enumerate(ws):
+        tq, ts, tz = dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda)
+        L.check(lib.w4a16_repack(tq.data_ptr(), ts.data_ptr(), tz.data_ptr(), pw[e].data_ptr(), ps[e].data_ptr(),
+                                 K, N, G, stream), "repack")
+    tx = dev_t(xs, cuda)
+    stride = M * N + 4
+    for cfg in ((4, 1, 8, -1), (2, 3, 8, -1), (4, 3, 4, -1), (2, 3, 1, -8), None):
+        out = torch.full((E * stride,), float("nan"), dtype=torch.float16, device=cuda)
+        if cfg is None:  # the library's launch shape
+            L.check(lib.w4a16_gemm_packed_f16_batched(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None, out.data_ptr(),
+                                                      stride, M, K, N, G, E, stream), "batched")
+        else:
+            L.check(lib.w4a16_gemm_packed_f16_batched_cfg(tx.data_ptr(), 0, pw.data_ptr(), ps.data_ptr(), None,
+                                                          out.data_ptr(), stride, M, K, N, G, E, *cfg, stream), "batched_cfg")
+        got = out.cpu().numpy()
+        for e, (qw, s, qz) in enumerate(ws):
+            want = orc.gemm_faithful(xs, qw, s, qz).astype(np.float32)
+            block = got[e * stride:e * stride + M * N].reshape(M, N).astype(np.float32)
+            assert np.allclose(block, want, rtol=RTOL, atol=2 * ATOL), (cfg, e)
+            assert np.isnan(got[e * stride + M * N:(e + 1) * stride]).all(), (cfg, e, "padding between problems written")
+
+
 def test_batched_argument_errors(L, cuda):
     lib = L.lib
     t = torch.zeros(4096, dtype=torch.uint8, device=cuda)
