@@ -219,3 +219,35 @@ def test_compiled_binding_takes_bf16(ops, cuda):
     assert torch.equal(y.view(torch.int16), ops.awq_gemm_packed_bf16(tx, ops.awq_repack(tq, ts, tz)).view(torch.int16))
     with pytest.raises(RuntimeError):
         native.ops.awq_gemm(tx.float(), tq, ts, tz, 8)
+
+
+def test_linear_method_with_bf16_activations(ops, cuda):
+    """`AWQLinearMethod` on bf16 activations: apply_weights through the bf16 kernels, the gated MLP's activation as two
+    separate steps (the fused epilogue is fp16 only), `residual += linear(x)` through the add-to-out epilogue."""
+    from vllm_quick_amd.layers.activation import gate_up_silu_and_mul
+    from vllm_quick_amd.layers.linear import MergedColumnParallelLinear, RowParallelLinear
+    from vllm_quick_amd.layers.quantization import AWQConfig
+    method = AWQConfig(4, 128, True).get_linear_method()
+    H, I, M = 512, 768, 6
+    gate_up = MergedColumnParallelLinear(H, [I, I], bias=False, params_dtype=torch.float16, linear_method=method).to(cuda)
+    down = RowParallelLinear(I, H, bias=False, params_dtype=torch.float16, linear_method=method).to(cuda)
+    raw = {}
+    for name, lin, (K, N) in (("gu", gate_up, (H, 2 * I)), ("down", down, (I, H))):
+        _, qw, s, qz = make(1, K, N, 128, seed=K)
+        raw[name] = (qw, s, qz)
+        lin.qweight.data.copy_(dev_t(qw, cuda))
+        lin.scales.data.copy_(dev_t(s, cuda))
+        lin.qzeros.data.copy_(dev_t(qz, cuda))
+    xb = orc.f32_to_bf16_bits((np.random.default_rng(4).standard_normal((M, H)) * 0.5).astype(np.float32))
+    tx = bf16_tensor(xb, cuda)
+    y = gate_up(tx)[0]
+    assert y.dtype == torch.bfloat16
+    check_gemm(bits_of(y), xb, *raw["gu"], "gate_up")
+    act = gate_up_silu_and_mul(gate_up, tx)
+    assert act.dtype == torch.bfloat16
+    assert torch.equal(act.view(torch.int16), (torch.nn.functional.silu(y[:, :I]) * y[:, I:]).view(torch.int16))
+    base = orc.f32_to_bf16_bits(np.random.default_rng(5).standard_normal((M, H)).astype(np.float32))
+    res = bf16_tensor(base, cuda).clone()
+    r = method.apply_weights_add_(down.linear_weights, act, res)
+    assert r.data_ptr() == res.data_ptr()
+    check_gemm(bits_of(res), bits_of(act), *raw["down"], "down + residual", base_bits=base)

@@ -172,8 +172,8 @@ class AWQLinearMethod(LinearMethodBase):
         reshaped_x = x.reshape(-1, x.shape[-1])
         num_tokens = x.shape[:-1].numel()
 
-        if self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold:
-            # (bit-identical dense weights from either layout)
+        if self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold and x.dtype == torch.float16:
+            # (bit-identical dense weights from either layout; fp16 only: there is no bf16 dequantise)
             dense = ops.awq_dequantize_packed(weights[_PACKED_KEY][1]) if dropped else \
                 ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
             out = torch.matmul(reshaped_x, dense)
@@ -203,7 +203,8 @@ class AWQLinearMethod(LinearMethodBase):
             weights["qweight"].shape[-1] * self.quant_config.pack_factor
         num_tokens = x.shape[:-1].numel()
         large = self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold
-        packed = None if (large or n_out % 32) else self._packed(weights)
+        # (the fused activation is built for fp16; bf16 activations take the two separate steps)
+        packed = None if (large or n_out % 32 or x.dtype != torch.float16) else self._packed(weights)
         if packed is None:
             y = self.apply_weights(weights, x, bias)
             half = n_out // 2
@@ -219,7 +220,10 @@ class AWQLinearMethod(LinearMethodBase):
         num_tokens = x.shape[:-1].numel()
         large = self.fp16_matmul_threshold is not None and num_tokens >= self.fp16_matmul_threshold
         packed = None if large else self._packed(weights)
-        if packed is None or not residual.is_contiguous() or residual.dtype != torch.float16:
+        if packed is not None and residual.is_contiguous() and residual.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+            ops.awq_gemm_packed_bf16(x.reshape(-1, x.shape[-1]), packed, bias=bias, out=residual.view(-1, residual.shape[-1]))
+            return residual
+        if packed is None or not residual.is_contiguous() or residual.dtype != torch.float16 or x.dtype != torch.float16:
             return residual.add_(self.apply_weights(weights, x, bias))
         ops.awq_gemm_packed_add_(residual.view(-1, residual.shape[-1]), x.reshape(-1, x.shape[-1]), packed, bias=bias)
         return residual
