@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline_m1    the M = 1 decode launch of the same layer (HBM-bound), N = 1 only,
   sweep          per-M kernel times of the whole M sweep (and of the stock-layout kernel, which serves a call
                  only when no packed copy can be made), N = 1 only,
-  sweep_bf16     the same layer with bf16 activations at 1, 16 and 128 rows (beside the fp16 times), N = 1 only,
+  sweep_bf16     the same layer with bf16 activations at 1, 16, 128 and 1024 rows (beside the fp16 times), N = 1 only,
   cpu_baseline   torch.matmul(x, dequant(W)) with the oracle's dequantiser on the host cores, N = 1 only,
   decode         Llama-2-7B-AWQ-shaped greedy decode tokens/s (benchmarks/llama_decode.py), N = 1 only,
   experts        Mixtral-8x7B-shaped expert block, batched launches vs per-expert loop, N = 1 only,
@@ -513,10 +513,10 @@ def main():
             out["sweep"] = sweep
             # bf16 activations on the same packed weights (an extension: the reference is fp16 only)
             bf = {}
-            for m in (1, 16, 128):
+            for m in (1, 16, 128, 1024):
                 xb = make_x(m, K, seed=m, device=device).to(torch.bfloat16)
                 us = time_launches([(lambda i=i: ops.awq_gemm_packed_bf16(xb, col[i])) for i in range(NBUF)], stream,
-                                   launches, args.warmup)
+                                   launches if m <= 512 else NBUF, args.warmup if m <= 512 else NBUF)
                 bf[str(m)] = {"us": us, "GBps": algorithmic_bytes(m, K, N, G) / us * 1e-3,
                               "TFLOPs": 2.0 * m * K * N / us * 1e-6, "fp16_us": sweep[str(m)]["us"] if str(m) in sweep else None}
             out["sweep_bf16"] = bf

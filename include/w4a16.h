@@ -211,15 +211,16 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
  * check against a float64 restatement of the definition above.  Epilogues: W4A16_EPI_NONE, W4A16_EPI_ADD_TO_OUT
  * (bf16 + bf16, rounded once); others return W4A16_E_SHAPE.  mt == 0: the library's launch shape (up to 16 rows
  * the decode kernel where K is a multiple of 128, else the streaming 16x16x32 kernel; beyond 16 rows the 32x32x16
- * kernel with private slabs where K is a multiple of 128);
+ * kernels where K is a multiple of 128: private slabs, and beyond 256 rows the shared slab where fp16 takes it);
  * mt > 0: (mt, t, waves) of the streaming kernel as built for bf16; mt == -16: (t, waves) of the decode kernel (up
- * to 16 rows, K a multiple of 128); other mt < 0: (-mt, t, kw = waves) of the 32x32x16 kernel as built for bf16
- * (all listed by w4a16_built_shape_bf16); W4A16_E_SHAPE otherwise.
+ * to 16 rows, K a multiple of 128); mt == -36: (t, nw = waves) of the shared-slab 32x32x16 kernel with four row
+ * tiles (K a multiple of 128, at least 256); other mt < 0: (-mt, t, kw = waves) of the private-slab 32x32x16 kernel as
+ * built for bf16 (all listed by w4a16_built_shape_bf16); W4A16_E_SHAPE otherwise.
  */
 int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* packed_sz, const void* bias, void* out,
                            int M, int K, int N, int G, int epilogue, int mt, int t, int waves, void* stream);
-/* The i-th built (mt, t, waves) of the bf16 kernels in shape[3] (mt == -16: the decode kernel, other mt < 0: the
- * 32x32x16 kernel); W4A16_E_SHAPE past the end. */
+/* The i-th built (mt, t, waves) of the bf16 kernels in shape[3] (mt == -16: the decode kernel, -36: the shared-slab
+ * 32x32x16 kernel, other mt < 0: the private-slab one); W4A16_E_SHAPE past the end. */
 int w4a16_built_shape_bf16(int i, int* shape);
 
 /*

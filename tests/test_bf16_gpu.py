@@ -50,7 +50,7 @@ DECODE_TAG = -16  # first entry of a built shape that names the decode kernel (u
 
 def refused(cfg, M, K):
     """Launch shapes that do not take the problem: the 32x32x16 and decode kernels want whole 128-k blocks, the decode
-    kernel up to 16 rows."""
+    kernel up to 16 rows.  (-36, t, nw) names the shared-slab 32x32x16 kernel: whole blocks, any row count.)"""
     return cfg is not None and cfg[0] < 0 and (K % 128 != 0 or (cfg[0] == DECODE_TAG and M > 16))
 
 
@@ -122,7 +122,7 @@ def test_weights_bit_exact_through_unit_rows(L, ops, cuda, G):
             assert not bad.any(), f"G={G} M={M} cfg={cfg}: {int(bad.sum())} differ, e.g. got {got[bad][:4]} want {canon[rows][bad][:4]}"
 
 
-@pytest.mark.parametrize("M", [1, 3, 16, 17, 33, 128])
+@pytest.mark.parametrize("M", [1, 3, 16, 17, 33, 128, 300, 1100])
 def test_gemm_within_rounding_of_float64(L, ops, cuda, M):
     K, N, G = 4096, 1376, 128
     xb, qw, s, qz = make(M, K, N, G, seed=40 + M)
@@ -196,11 +196,11 @@ def test_operator_mirror_and_errors(L, ops, cuda):
 
 
 def test_full_size_layer(L, ops, cuda):
-    """The benchmark layer (4096 x 11008, group 128) at 1, 16 and 128 rows."""
+    """The benchmark layer (4096 x 11008, group 128) at 1, 16, 128 and 512 rows."""
     K, N, G = 4096, 11008, 128
     _, qw, s, qz = make(1, K, N, G, seed=77)
     packed = ops.awq_repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
-    for M in (1, 16, 128):
+    for M in (1, 16, 128, 512):
         xb = orc.f32_to_bf16_bits((np.random.default_rng(M).standard_normal((M, K)) * 0.25).astype(np.float32))
         y = ops.awq_gemm_packed_bf16(bf16_tensor(xb, cuda), packed)
         check_gemm(bits_of(y), xb, qw, s, qz, f"full size M={M}")

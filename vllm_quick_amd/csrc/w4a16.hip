@@ -521,6 +521,7 @@ int w4a16_gemm_packed_f16_batched(const void* x, long long x_batch_stride, const
 // long enough to give every wave a block, up to three column tiles per workgroup), two row tiles beyond (8 waves,
 // row blocks of 32 in gridDim.y, as many column tiles per workgroup as still leave a workgroup per CU).
 constexpr int kBf16DecodeTag = -16;  // first entry of a bf16 launch shape that names the decode kernel
+constexpr int kBf16SharedTag = -36;  // ... the shared-slab 32x32x16 kernel (four row tiles)
 static void choose_bf16(int M, int K, int N, int* mt, int* t, int* waves) {
   const int NT = ceil_div(N, 16), KB = ceil_div(K, 128);
   if (M <= 16) {
@@ -554,6 +555,16 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
     const bool wide_ok = K % 128 == 0 && (long long)a.NT * a.KBS * 1024 < (1LL << 32) &&
                          (long long)M * K * 2 + kDmaImmBias < (1LL << 32);
     if (M > 16 && wide_ok) {
+      // Beyond 256 rows the shared-slab kernel where the fp16 chooser takes it: its shape if that is built for bf16,
+      // else the built one nearest in rows per launch.
+      if (M > 256 && K >= 256) {
+        const Choice c = choose_mfma32(M, K, N, 1);
+        if (c.a > 1) {
+          int st = c.t, snw = c.a;
+          if (!(c.mt == 4 && wide_shared_bf16_built(4, st, snw))) st = M >= 768 && M < 2048 ? 3 : 2, snw = M >= 2048 ? 8 : 4;
+          return dispatch_wide_shared(a, 4, st, snw, static_cast<hipStream_t>(stream), 1, false, true);
+        }
+      }
       const bool two = M >= 48;
       return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
                            nullptr, 0, true);
@@ -568,6 +579,8 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
   if (mt < 0) {
     if (mt == kBf16DecodeTag)  // (tag, t, waves): the decode kernel, up to 16 rows
       return dispatch_decode(a, t, waves, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
+    if (mt == kBf16SharedTag)  // (tag, t, nw): the shared-slab 32x32x16 kernel with four row tiles
+      return dispatch_wide_shared(a, 4, t, waves, static_cast<hipStream_t>(stream), 1, false, true);
     // (-mt, t, waves as kw): the 32x32x16 kernel, as w4a16_gemm_packed_f16_wide_cfg names its shapes
     return dispatch_wide(a, -mt, t, waves, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, true);
   }
@@ -584,6 +597,7 @@ int w4a16_built_shape_bf16(int i, int* shape) {
 #define X(T_, W_) {kBf16DecodeTag, T_, W_},
       W4A16_FOR_EACH_DECODE(X)  // the decode kernel
 #undef X
+      {kBf16SharedTag, 2, 4}, {kBf16SharedTag, 3, 4}, {kBf16SharedTag, 2, 8},  // the shared-slab kernel (wide_shared_bf16_built)
   };
   if (i >= (int)(sizeof(built) / sizeof(built[0]))) return W4A16_E_SHAPE;
   for (int j = 0; j < 3; ++j) shape[j] = built[i][j];

@@ -520,6 +520,10 @@ constexpr bool wide_double_slab(int mt, int kw) { return W4A16_WIDE_DBL && mt ==
 constexpr bool wide_bf16_built(int mt, int t, int kw) { return (mt == 2 && t == 3 && kw == 4) || (mt == 1 && t == 2 && kw == 8); }
 constexpr int wide_slices_per_owner(int mt, int t, bool act) { return act ? ((t * mt + 1) / 2) * 2 : t * mt; }
 inline size_t wide_ws_bytes(long long tiles, int splits, int mt, int t, bool act);
+// shared-slab shapes also built for bf16 activations (a few hundred rows and more)
+constexpr bool wide_shared_bf16_built(int mt, int t, int nw) {
+  return mt == 4 && ((t == 2 && nw == 4) || (t == 3 && nw == 4) || (t == 2 && nw == 8));
+}
 // (mt, t, nw) of the shared-slab 32x32x16 kernel
 #define W4A16_FOR_EACH_WIDE_SHARED(X) X(4, 1, 8) X(4, 2, 8) X(2, 1, 8) X(2, 2, 8) X(2, 3, 8) X(4, 3, 4) X(4, 2, 4)
 // (t, waves) of the decode kernel; the fused activation takes the even t
@@ -606,7 +610,7 @@ W4A16_HIDDEN int dispatch_wide(const GemmArgs& a, int mt, int t, int kw, hipStre
                                bool act = false, int splits = 1, void* ws = nullptr, size_t ws_bytes = 0,
                                bool bf16 = false);
 W4A16_HIDDEN int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch = 1,
-                                      bool act = false);
+                                      bool act = false, bool bf16 = false);
 // `depth`: blocks a wave keeps in flight (1 or 2; 0 = the default for the shape)
 W4A16_HIDDEN int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batch, bool act, int splits,
                                  void* ws, size_t ws_bytes, int depth = 0, bool bf16 = false);

@@ -26,10 +26,16 @@ namespace {
 // kernels'.  One workgroup barrier per 128-k block: after it every wave's share of the block's slab has
 // landed (each waits for its own DMA before arriving) and the slab of the block before last is free.
 
-template <int MT, int T, int NW, int SZS, bool ACT = false>
+// AT: the activation / output type (fp16, or bf16 for the plain GEMM of a few shapes; see dequant_word_bf16).
+template <int MT, int T, int NW, int SZS, bool ACT = false, class AT = ActF16>
 __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1)) gemm_wide_shared_kernel(int n_slices, int m_blocks, int panel_rows,
                                                                    const GemmArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+  typedef typename AT::elem elem;
+  typedef typename AT::x4 ex4;
+  typedef typename AT::x8 ex8;
+  typedef typename AT::consts SZc;
+  static_assert(!ACT || std::is_same<AT, ActF16>::value, "the fused activation is built for fp16");
   fetch_args_now(ga);
   asm volatile("" ::"s"(n_slices), "s"(m_blocks), "s"(panel_rows));
   if (ga.mask != nullptr && ga.mask[blockIdx.z] == 0) return;
@@ -190,28 +196,28 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
       }
     }
   };
-  auto read_x = [&](int ks, int base, f16x8 (&xf)[MT]) {
+  auto read_x = [&](int ks, int base, ex8 (&xf)[MT]) {
 #ifdef W4A16_SH_DBG
     if ((W4A16_SH_DBG & 2) && ks > 0) return;  // ablation: one fragment read per block
 #endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      xf[mt] = *reinterpret_cast<const f16x8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
+      xf[mt] = *reinterpret_cast<const ex8*>(smem_raw + base + (((2 * ks + h) ^ xsw) << 4) + mt * 8192);
 #ifdef W4A16_CHECK_DMA
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       dma_check(__builtin_bit_cast(u32x4, xf[mt]), &g_dma_state[0]);
 #endif
   };
-  auto convert = [&](int kstep, int t, const WSet& b, SZ (&c)[T]) {
-    if (kstep % (2 * SZS) == 0) c[t] = expand_sz(b.sz[t][kstep / (2 * SZS)]);
+  auto convert = [&](int kstep, int t, const WSet& b, SZc (&c)[T]) {
+    if (kstep % (2 * SZS) == 0) c[t] = AT::expand(b.sz[t][kstep / (2 * SZS)]);
 #ifdef W4A16_SH_DBG
-    if (W4A16_SH_DBG & 1) return __builtin_bit_cast(f16x8, b.q[t][kstep & 1]);  // ablation: no conversion
+    if (W4A16_SH_DBG & 1) return __builtin_bit_cast(ex8, b.q[t][kstep & 1]);  // ablation: no conversion
 #endif
-    return dequant_word(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
+    return AT::dequant(b.q[t][kstep & 1][kstep >> 1], c[t], dqc);
   };
-  auto math = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0) {
-    f16x8 af[T + 1];
+  auto math = [&](int kstep, const WSet& b, SZc (&c)[T], const ex8 (&xf)[MT], ex8& af0) {
+    ex8 af[T + 1];
     af[0] = af0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -221,7 +227,7 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
         af[T] = convert(kstep + 1, 0, b, c);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xf[mt], acc[t][mt], 0, 0, 0);
+        acc[t][mt] = AT::mfma32(af[t], xf[mt], acc[t][mt]);
     }
     if (kstep + 1 < 8) af0 = af[T];
     constexpr int per = (13 + MT - 1) / MT;
@@ -234,18 +240,18 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   // The same arithmetic tile by tile, each tile's matrix instructions and the next tile's conversion in a scheduling
   // region of their own, and `between(slot)` (slot = T kstep + t: a request for the next blocks) issued in program
   // order behind tile t's region, in the shadow of its last matrix instruction.
-  auto math_spread = [&](int kstep, const WSet& b, SZ (&c)[T], const f16x8 (&xf)[MT], f16x8& af0, auto&& between) {
-    f16x8 af = af0;
+  auto math_spread = [&](int kstep, const WSet& b, SZc (&c)[T], const ex8 (&xf)[MT], ex8& af0, auto&& between) {
+    ex8 af = af0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      f16x8 nx = af;
+      ex8 nx = af;
       if (t + 1 < T)
         nx = convert(kstep, t + 1, b, c);
       else if (kstep + 1 < 8)
         nx = convert(kstep + 1, 0, b, c);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[mt], acc[t][mt], 0, 0, 0);
+        acc[t][mt] = AT::mfma32(af, xf[mt], acc[t][mt]);
       constexpr int per = (13 + MT - 1) / MT;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -262,9 +268,9 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
   // Four k-steps (half HB of a block) from weight set `b`.  On entry `xa` holds the fragments of the half's first
   // k-step and `af0` tile 0's converted weights for it; on exit `af0` holds tile 0's weights of the k-step that
   // follows the half (if the block has one): the conversion runs one tile ahead of the matrix instructions.
-  auto half = [&](auto hb_, int base, const WSet& b, SZ (&c)[T], f16x8& af0, f16x8 (&xa)[MT]) {
+  auto half = [&](auto hb_, int base, const WSet& b, SZc (&c)[T], ex8& af0, ex8 (&xa)[MT]) {
     constexpr int K0 = 4 * decltype(hb_)::value;
-    f16x8 xb[MT];
+    ex8 xb[MT];
 #pragma unroll
     for (int k2 = 0; k2 < 4; k2 += 2) {
       read_x(K0 + k2 + 1, base, xb);
@@ -316,10 +322,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
         for (int u = 0; u < PER; ++u)
           if (slot * PER + u < OPS) request(lw, dma, slot * PER + u, i + 1, goff, nxt, i + RING - 1, (i + RING - 1) % RING);
       };
-      SZ c[T];
-      f16x8 xa[MT], xb[MT];
+      SZc c[T];
+      ex8 xa[MT], xb[MT];
       read_x(0, base, xa);
-      f16x8 af0 = convert(0, 0, cur, c);
+      ex8 af0 = convert(0, 0, cur, c);
 #pragma unroll
       for (int k2 = 0; k2 < 8; k2 += 2) {
         read_x(k2 + 1, base, xb);
@@ -335,10 +341,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
     __builtin_amdgcn_sched_barrier(0);  // (the waits above count a block's requests, whatever their order)
     if constexpr (LW) load_w(i + 1, nxt);
     __builtin_amdgcn_sched_barrier(0);
-    SZ c[T];
-    f16x8 xa[MT], xb[MT];
+    SZc c[T];
+    ex8 xa[MT], xb[MT];
     read_x(0, base, xa);
-    f16x8 af0 = convert(0, 0, cur, c);
+    ex8 af0 = convert(0, 0, cur, c);
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2 += 2) {
       read_x(k2 + 1, base, xb);
@@ -403,10 +409,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
         if constexpr (LW) load_w(j + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         const int base = slab_of(j);
-        SZ c[T];
-        f16x8 xa[MT];
+        SZc c[T];
+        ex8 xa[MT];
         read_x(0, base, xa);
-        f16x8 af0 = convert(0, 0, cur, c);
+        ex8 af0 = convert(0, 0, cur, c);
         half(Flag<0>{}, base, cur, c, af0, xa);
         read_x(4, base, xa);
         half(Flag<1>{}, base, cur, c, af0, xa);
@@ -434,10 +440,10 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
         if constexpr (LW) load_w(b + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         const int base = slab_of(b);
-        SZ c[T];
-        f16x8 xa[MT];
+        SZc c[T];
+        ex8 xa[MT];
         read_x(0, base, xa);
-        f16x8 af0 = convert(0, 0, cur, c);
+        ex8 af0 = convert(0, 0, cur, c);
         half(Flag<0>{}, base, cur, c, af0, xa);
         if constexpr (BAR) {
           W4A16_DMA_WAIT(NXT ? ND + WL : WL);
@@ -499,18 +505,27 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f16x4*>(stage + wr + ((q ^ wsw) << 4)) =
-              f16x4{(f16)acc[t][mt][4 * q], (f16)acc[t][mt][4 * q + 1], (f16)acc[t][mt][4 * q + 2], (f16)acc[t][mt][4 * q + 3]};
+          *reinterpret_cast<ex4*>(stage + wr + ((q ^ wsw) << 4)) =
+              AT::round(f32x4{acc[t][mt][4 * q], acc[t][mt][4 * q + 1], acc[t][mt][4 * q + 2], acc[t][mt][4 * q + 3]});
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           const int row = 16 * pass + rrow;
-          f16x8 hv = *reinterpret_cast<const f16x8*>(stage + row * 64 + ((rch ^ ((row >> 1) & 3)) << 4));
+          const ex8 hv = *reinterpret_cast<const ex8*>(stage + row * 64 + ((rch ^ ((row >> 1) & 3)) << 4));
           const int m = m0 + mt * 32 + row, nn = (ct0 + t) * 32 + 8 * rch;
           if (m < a.M && nn < a.N) {  // (N is a multiple of 8: a chunk is inside or outside as a whole)
-            if (a.bias != nullptr) hv += *reinterpret_cast<const f16x8*>(a.bias + nn);
-            f16x8* dst = reinterpret_cast<f16x8*>(a.out + (size_t)m * a.N + nn);
-            if (a.add_out) hv = *dst + hv;  // fp16 + fp16; one lane owns each element
-            *dst = hv;
+            ex4 lo = __builtin_shufflevector(hv, hv, 0, 1, 2, 3), hi = __builtin_shufflevector(hv, hv, 4, 5, 6, 7);
+            if (a.bias != nullptr) {
+              const elem* bias = reinterpret_cast<const elem*>(a.bias) + nn;
+              lo = AT::add(lo, *reinterpret_cast<const ex4*>(bias));
+              hi = AT::add(hi, *reinterpret_cast<const ex4*>(bias + 4));
+            }
+            ex8* dst = reinterpret_cast<ex8*>(reinterpret_cast<elem*>(a.out) + (size_t)m * a.N + nn);
+            if (a.add_out) {  // fp16 + fp16 (bf16 + bf16, rounded once); one lane owns each element
+              const ex8 old = *dst;
+              lo = AT::add(__builtin_shufflevector(old, old, 0, 1, 2, 3), lo);
+              hi = AT::add(__builtin_shufflevector(old, old, 4, 5, 6, 7), hi);
+            }
+            *dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
         }
       }
@@ -518,8 +533,8 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
 #ifdef W4A16_STAMPS
     if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
 #endif
-    return;
-  }
+  } else {
+  static_assert(std::is_same<AT, ActF16>::value, "fp16 only from here");
   // straight from the accumulators: register group q of tile (t, mt) is token 32 mt + r32, columns 8 q + 4 h .. + 3
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -558,11 +573,12 @@ __global__ void __launch_bounds__(64 * NW, (ring_slabs<MT, T, NW>() == 2 ? 2 : 1
 #ifdef W4A16_STAMPS
   if (lane == 0 && STAMP_OK) g_stamps[((size_t)blockIdx.x * NWAVES + w) * 32 + 31] = __builtin_amdgcn_s_memrealtime();
 #endif
+  }
 #endif
 }
 
 template <int MT, int T, int NW>
-int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
+int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act, bool bf16) {
   constexpr int lds = ring_slabs<MT, T, NW>() * MT * 32 * 256;  // ring of slabs
   static_assert(lds <= 160 * 1024, "LDS budget");
   // whole 128-k blocks, at least two of them, and 32-bit byte offsets
@@ -573,7 +589,20 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
   const int m_blocks = ceil_div(a.M, MT * 32);
   const int blocks = ceil_div((long long)n_slices * m_blocks, 8) * 8;
   void (*kern)(int, int, int, const GemmArgs) = nullptr;
-  if (act) {
+  if (bf16) {
+    // bf16 activations: built for a few shapes, plain GEMM (+ bias, + add-to-out)
+    if constexpr (wide_shared_bf16_built(MT, T, NW)) {
+      if (act || batch != 1) return W4A16_E_SHAPE;
+      if (a.G % 128 == 0)
+        kern = gemm_wide_shared_kernel<MT, T, NW, 4, false, ActBf16>;
+      else if (a.G == 64)
+        kern = gemm_wide_shared_kernel<MT, T, NW, 2, false, ActBf16>;
+      else
+        kern = gemm_wide_shared_kernel<MT, T, NW, 1, false, ActBf16>;
+    } else {
+      return W4A16_E_SHAPE;
+    }
+  } else if (act) {
     if (a.G % 128 == 0)
       kern = gemm_wide_shared_kernel<MT, T, NW, 4, true>;
     else if (a.G == 64)
@@ -604,9 +633,9 @@ int launch_wide_shared(const GemmArgs& a, hipStream_t s, int batch, bool act) {
 
 }  // namespace
 
-int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch, bool act) {
+int dispatch_wide_shared(const GemmArgs& a, int mt, int t, int nw, hipStream_t s, int batch, bool act, bool bf16) {
 #define X(MT_, T_, NW_) \
-  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch, act);
+  if (mt == MT_ && t == T_ && nw == NW_) return launch_wide_shared<MT_, T_, NW_>(a, s, batch, act, bf16);
   W4A16_FOR_EACH_WIDE_SHARED(X)
 #undef X
   return W4A16_E_SHAPE;
