@@ -557,14 +557,15 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
     if (M > 16 && wide_ok) {
       // Beyond 256 rows the shared-slab kernel where the fp16 chooser takes it: its shape if that is built for bf16,
       // else the built one nearest in rows per launch.
-      if (M > 256 && K >= 256) {
-        const Choice c = choose_mfma32(M, K, N, 1);
-        if (c.a > 1) {
-          int st = c.t, snw = c.a;
-          if (!(c.mt == 4 && wide_shared_bf16_built(4, st, snw))) st = M >= 768 && M < 2048 ? 3 : 2, snw = M >= 2048 ? 8 : 4;
-          return dispatch_wide_shared(a, 4, st, snw, static_cast<hipStream_t>(stream), 1, false, true);
-        }
+      const Choice c = choose_mfma32(M, K, N, 1);
+      if (M > 256 && K >= 256 && c.a > 1) {
+        int st = c.t, snw = c.a;
+        if (!(c.mt == 4 && wide_shared_bf16_built(4, st, snw))) st = M >= 768 && M < 2048 ? 3 : 2, snw = M >= 2048 ? 8 : 4;
+        return dispatch_wide_shared(a, 4, st, snw, static_cast<hipStream_t>(stream), 1, false, true);
       }
+      // the fp16 chooser's private-slab shape where that is built for bf16 (128 x 96 tiles at 129-256 rows of wide layers)
+      if (c.a == 1 && c.b < 0 && wide_bf16_built(c.mt, c.t, -c.b))
+        return dispatch_wide(a, c.mt, c.t, -c.b, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, true);
       const bool two = M >= 48;
       return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
                            nullptr, 0, true);
@@ -593,7 +594,7 @@ int w4a16_built_shape_bf16(int i, int* shape) {
 #define X(MT_, T_, W_) {MT_, T_, W_},
       W4A16_FOR_EACH_BF16(X)
 #undef X
-      {-2, 3, 4}, {-1, 2, 8},  // the 32x32x16 kernel (wide_bf16_built)
+      {-2, 3, 4}, {-1, 2, 8}, {-4, 3, 4}, {-1, 3, 4}, {-2, 2, 4},  // the private-slab 32x32x16 kernel (wide_bf16_built)
 #define X(T_, W_) {kBf16DecodeTag, T_, W_},
       W4A16_FOR_EACH_DECODE(X)  // the decode kernel
 #undef X

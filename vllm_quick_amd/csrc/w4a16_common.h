@@ -517,7 +517,10 @@ inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
 #endif
 constexpr bool wide_double_slab(int mt, int kw) { return W4A16_WIDE_DBL && mt == 2 && kw == 4; }
 // private-slab shapes also built for bf16 activations (17 rows and more)
-constexpr bool wide_bf16_built(int mt, int t, int kw) { return (mt == 2 && t == 3 && kw == 4) || (mt == 1 && t == 2 && kw == 8); }
+constexpr bool wide_bf16_built(int mt, int t, int kw) {
+  return (mt == 2 && t == 3 && kw == 4) || (mt == 1 && t == 2 && kw == 8) || (mt == 4 && t == 3 && kw == 4) ||
+         (mt == 1 && t == 3 && kw == 4) || (mt == 2 && t == 2 && kw == 4);
+}
 constexpr int wide_slices_per_owner(int mt, int t, bool act) { return act ? ((t * mt + 1) / 2) * 2 : t * mt; }
 inline size_t wide_ws_bytes(long long tiles, int splits, int mt, int t, bool act);
 // shared-slab shapes also built for bf16 activations (a few hundred rows and more)
