@@ -140,11 +140,12 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false, bool hav
   // From 33 rows: 10-40 % faster than the 16x16x32 kernels on every layer shape measured, and ahead of
   // dequantise + dense GEMM at every row count.
   if (wide_ok && M > 32) return choose_mfma32(M, K, N, batch, have_ws);
-  // 21-32 rows of a single problem: 5-25 % over the 16x16x32 kernels from K = 2048 up (at 24 / 32 rows,
+  // 17-32 rows of a single problem: 5-30 % over the 16x16x32 kernels from K = 2048 up (at 24 / 32 rows,
   // 4096 x 11008: 10.2 / 10.6 against 11.6 / 11.6 us; 4096 x 4096: 7.8 / 7.9 against 9.5 / 9.8; 4096 x 14336:
-  // 11.0 / 11.4 against 14.6 / 14.8; 8192 x 1280: 12.0 against 15.4; 4096 x 1376: 7.7 / 7.8 against 9.2 / 10.6).
-  // At 17 rows the streaming kernel, whose cost grows with the rows, is still ahead on narrow layers and long K
-  // (11008 x 4096: 16.4 against 18.9), and at K = 1024 always.
+  // 11.0 / 11.4 against 14.6 / 14.8; 8192 x 1280: 12.0 against 15.4; 4096 x 1376: 7.7 / 7.8 against 9.2 / 10.6;
+  // at 17 / 20 rows, 16 layer shapes: 4096 x 11008 9.3 / 9.0 against 11.2 / 11.7 for the streaming kernel, 4096 x 14336
+  // 9.7 against 14.3 / 13.7, 11008 x 4096 15.3 against 16.9 / 18.7, 4096 x 22016 13.9 against 16.4; level within 4 %
+  // at 17 rows on 4096 x 4096 and 4096 x 1376).  At K = 1024 the streaming kernel stays ahead.
   if (wide_ok && batch == 1 && M > kWideFromRows && K >= 2048) return choose_mfma32(M, K, N, batch);
   const int mtiles = ceil_div(M, 16);
   const int cus = 256;

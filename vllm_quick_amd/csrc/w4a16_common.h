@@ -479,7 +479,7 @@ inline int fill_args(GemmArgs* a, const void* x, const void* packed_w, const voi
 // to each other up to 8 of them, panels of this many beyond (map_workgroup).
 constexpr int kPanelRows = 4;
 // The 32x32x16 kernels serve single problems with more rows than this (and K >= 2048).
-constexpr int kWideFromRows = 20;
+constexpr int kWideFromRows = 16;
 
 inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
   if (panel_rows != m_blocks || items * m_blocks >= 65536) return 0;
