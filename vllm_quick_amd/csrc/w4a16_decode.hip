@@ -31,9 +31,16 @@ namespace {
 // and wave would not fit LDS), the waves park whole 16 x 16 partial tiles, and waves 0..H-1 each sum one tile.
 // AT: the activation / output type (fp16 or bf16; the weights of the bf16 path are bf16((q - z) * s), see
 // dequant_word_bf16).
-template <int T, int W, int DB, int SZS, bool ACT = false, bool XLDS = true, class AT = ActF16>
+// XM: how the activations reach the matrix instruction.  1: up to 4 rows, all of a wave's blocks staged in LDS up
+// front (above).  0: 5-16 rows, B fragments straight from L2.  2: 5-16 rows through a ring of DB slots of 4 KiB per
+// wave: a block's 16 rows x 256 bytes arrive by four LDS-DMA instructions of 4 rows x 256 contiguous bytes (whole
+// cache lines, where a fragment load touches 16 separate 64-byte pieces; rows past M - 1 repeat the last row), chunk
+// c of row r at 16-byte position c ^ r of the row, so that the ds_read_b128 fragment reads are conflict-free; the
+// slot of block b is refilled for block b + DB right after the block's first unit has consumed its fragments.
+template <int T, int W, int DB, int SZS, bool ACT = false, int XM = 1, class AT = ActF16>
 __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
+  constexpr bool XLDS = XM == 1, XRING = XM == 2;
   typedef typename AT::elem elem;
   typedef typename AT::x4 ex4;
   typedef typename AT::x8 ex8;
@@ -104,15 +111,33 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   // LDS-DMA of one block's activations (1 KiB of the wave's private LDS): lane -> row lane >> 4 (rows past
   // M - 1 repeat it), 16-byte position lane & 15 of the row, which holds chunk (lane & 15) ^ 4 (lane >> 4)
   const uint32_t xlane = ((uint32_t)min(kq, a.M - 1) * a.K + ((n16 ^ (4 * kq)) * 8)) * 2u;
-  const int xwave = w * nb_max * 1024;
+  const int xwave = XRING ? w * (DB * 4096) : w * nb_max * 1024;
   // B fragment of k-step j: row min(n16, M - 1) (the matrix instruction's columns past M - 1 are never stored),
   // chunk 4 j + kq
   int xrd[4];
   {
     const int rr = min(n16, a.M - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xrd[j] = xwave + rr * 256 + ((4 * (j ^ rr) + kq) << 4);
+    for (int j = 0; j < 4; ++j)
+      xrd[j] = XRING ? xwave + n16 * 256 + (((4 * j + kq) ^ n16) << 4) : xwave + rr * 256 + ((4 * (j ^ rr) + kq) << 4);
   }
+  // ring: DMA i of a block fills rows 4 i .. 4 i + 3: lane -> row 4 i + (lane >> 4), position lane & 15
+  uint32_t xring[XRING ? 4 : 1];
+  if constexpr (XRING) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * i + kq;
+      xring[i] = ((uint32_t)min(row, a.M - 1) * a.K + ((n16 ^ row) * 8)) * 2u;
+    }
+  }
+  auto dma_ring = [&](int kb, int slot) {
+    if constexpr (XRING) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + slot * 4096 + i * 1024), 16, xring[i],
+                                                 kb * 256, 0, 0);
+    }
+  };
 
   f32x4 acc[T];
 #pragma unroll
@@ -160,18 +185,31 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     if constexpr (XLDS) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + bi * 1024);
+    } else if constexpr (XRING) {
+      // The slot's DMA was issued ahead of this block's weights; younger than it are those T * UL loads and, with two
+      // blocks in flight and a block after this one, that block's DMA and weights.  (The counter has 6 bits.)
+      constexpr int YOUNGER = (DB == 2 && XNEXT) ? 2 * T * UL + 4 : T * UL;
+      wait_vmcnt<(YOUNGER < 63 ? YOUNGER : 63)>();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + (bi % DB) * 4096);
     } else if constexpr (XNEXT) {
       load_x(kb_xnext, xnext);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if constexpr (XLDS)
+      if constexpr (XLDS || XRING)
         compute_unit(t, u[t], xl);
       else
         compute_unit(t, u[t], xcur);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (REFILL) {
+        // (ring: the first unit has used all four fragments, their slot takes the block DB ahead; DMA before weights)
+        if (XRING && t == 0) {
+          dma_ring(kb_refill, bi % DB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         load_unit(t, kb_refill, u[t]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -188,6 +226,8 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       for (int bi = 0; bi < nblk; ++bi)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + bi * 1024), 16, xlane,
                                                  kb_of(bi) * 256, 0, 0);
+    } else if constexpr (XRING) {
+      dma_ring(kb0, 0);
     } else {
       load_x(kb0, xa);
     }
@@ -198,6 +238,9 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     if constexpr (DB == 2) {
       // (a wave with a single block fetches it twice: nothing in the prologue is conditional)
       const int kb1 = nblk > 1 ? kb_of(1) : kb0;
+      __builtin_amdgcn_sched_barrier(0);
+      dma_ring(kb1, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < T; ++t) load_unit(t, kb1, u1[t]);
     }
@@ -248,7 +291,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   // sums the W partials of every (tile, token, 4-column group), one lane each.
   if constexpr (!XLDS) {
     // 5-16 rows: whole partial tiles (1 KiB per wave and tile), wave ti sums tile ti (and its up-half twin)
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (XRING ? W * DB * 4096 : 0));  // (behind the ring: other waves may still read theirs)
 #pragma unroll
     for (int t = 0; t < T; ++t) red[(w * T + t) * 64 + lane] = acc[t];
     __syncthreads();
@@ -387,7 +430,13 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   const int kb_per_split = ceil_div(a.KB, splits);
   splits = ceil_div(a.KB, kb_per_split);  // no empty split
   const int nb_max = ceil_div(kb_per_split, W);
-  const size_t lds = decode_lds_bytes(T, W, nb_max + 1, a.M, a.G);  // (+ 1: a wave may take a block from another)
+  // 5-16 rows: through the ring where DB slots of 4 KiB per wave fit beside the partial tiles, else fragments from L2
+#ifndef W4A16_DECODE_RING
+#define W4A16_DECODE_RING 1
+#endif
+  constexpr size_t ring_lds = (size_t)W * DB * 4096 + (size_t)W * T * 1024;
+  const bool ring = W4A16_DECODE_RING && !xlds && ring_lds <= 160 * 1024;
+  const size_t lds = ring ? ring_lds : decode_lds_bytes(T, W, nb_max + 1, a.M, a.G);  // (+ 1: a wave may take a block from another)
   if (lds > 160 * 1024) return W4A16_E_SHAPE;
   const int tiles = act ? a.NT / 2 : a.NT, per_wg = act ? T / 2 : T;
   const int gx = ceil_div(tiles, per_wg);
@@ -410,14 +459,17 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   e.splits = splits, e.gx = gx;
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
   const int szs = a.G % 128 == 0 ? 4 : a.G == 64 ? 2 : 1;
+  constexpr int kRingXm = ring_lds <= 160 * 1024 ? 2 : 0;  // (no ring instantiation for shapes it never fits)
 #define W4A16_PICK(SZS_)                                                                         \
   if (szs == SZS_) {                                                                             \
     if (act) {                                                                                   \
-      if constexpr (kAct) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, true, true, AT>       \
-                                      : gemm_decode_kernel<T, W, DB, SZS_, true, false, AT>;     \
+      if constexpr (kAct) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, true, 1, AT>          \
+                                 : ring ? gemm_decode_kernel<T, W, DB, SZS_, true, kRingXm, AT>  \
+                                        : gemm_decode_kernel<T, W, DB, SZS_, true, 0, AT>;       \
     } else {                                                                                     \
-      if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, true, AT>    \
-                                        : gemm_decode_kernel<T, W, DB, SZS_, false, false, AT>;  \
+      if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, 1, AT>          \
+                                   : ring ? gemm_decode_kernel<T, W, DB, SZS_, false, kRingXm, AT>  \
+                                          : gemm_decode_kernel<T, W, DB, SZS_, false, 0, AT>;       \
     }                                                                                            \
   }
   W4A16_PICK(4) W4A16_PICK(2) W4A16_PICK(1)
