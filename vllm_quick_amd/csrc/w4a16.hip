@@ -261,6 +261,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false, bool hav
 // shape chosen (4-7 % faster at 5-16 rows, 8-20 % at up to 4).  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
 // over K as well.
 Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool have_ws) {
+  // 17-32 rows: the decode kernel with two 16-row tiles, in the launch shape it takes at 16 rows, where that shape is
+  // built for two row tiles (plain GEMM).
+  if (M > kDecodeMaxRowsL2 && M <= kDecodeMaxRowsTwo && !act && K % 128 == 0) {
+    Choice c16 = choose_with_decode(kDecodeMaxRowsL2, K, N, G, batch, act, false);
+    if (c16.splits > 0 && decode_two_row_tiles_built(c16.t, c16.a, 1)) {
+      c16.splits = 1;
+      return c16;
+    }
+  }
   Choice c = choose_cfg(M, K, N, batch, act, have_ws);
   if (c.tiled || c.mt != 1 || M > kDecodeMaxRowsL2) return c;
   GemmArgs probe;
