@@ -240,7 +240,8 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
- * The decode kernel (up to 16 rows; the K split up to 4 rows and 4 tiles or tile pairs per workgroup) with an
+ * The decode kernel (up to 16 rows, and 17-32 rows of the plain GEMM with t <= 2 and 16 waves; the K split up to 4
+ * rows and 4 tiles or tile pairs per workgroup) with an
  * explicit launch shape, for tuning and tests;
  * batching and epilogues as for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
  * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
@@ -323,7 +324,7 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
  *                MFMA32      (mt, t, splits, kw)    32-row / 32-column tiles, private slabs per wavefront
  *                                                   (splits = 1 unless a workspace lets K be split over workgroups)
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
- *                DECODE      (1, t, waves, splits)  up to 16 rows
+ *                DECODE      (1, t, waves, splits)  up to 16 rows (32 with t <= 2 and 16 waves)
  * w4a16_launch_shape takes no group size: it answers for a group size the decode kernel admits (32, 64 or a
  * multiple of 128, i.e. every AWQ checkpoint in use); for another multiple of 32 the launches it reports as
  * DECODE are made by the streaming kernel with the same (t, waves).  w4a16_launch_shape_ws takes the group size.
