@@ -246,7 +246,8 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
  * batching and epilogues as for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
  * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
  * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and, up to 4 rows, stages its activations
- * in a private piece of LDS (5-16 rows: fragments straight from L2).  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
+ * in a private piece of LDS (5-32 rows: a ring of LDS slots filled block by block, or fragments straight from L2 where
+ * the ring does not fit).  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
  * `workspace`, and the one that arrives last adds them in split order, so the result does not depend on timing.
  * `workspace` (16-byte aligned; may be NULL when splits == 1) must hold w4a16_decode_workspace_bytes(...) bytes,
  * zero before its first use: the kernels return every counter they touch to zero, so one buffer serves any
