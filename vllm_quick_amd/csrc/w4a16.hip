@@ -89,9 +89,9 @@ struct Choice {
 // shapes x 14 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral, 2/4/8-way shards of the
 // benchmark layer) x 48-4096 rows (scripts/exp_shared_sweep.py), then each shape's pair scaled by a common factor
 // of 0.90-1.10 where that lowers the loss of the CHOICE (scripts/fit_chooser.py --tune; whole rounds of 256
-// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.6 %
-// on two sweeps of the current kernels (2.8 % with the constants fitted before the shared-slab kernel's stores were
-// re-arranged); with each layer shape held out of fit and tuning in turn, 1.0 % (worst 14 %).  The private-slab kernel splits K
+// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.5 %
+// on three sweeps of the current kernels, 33-4096 rows (2.8 % with the constants fitted before the shared-slab
+// kernel's stores were re-arranged); with each layer shape held out of fit and tuning in turn, 0.8 % (worst 13 %).  The private-slab kernel splits K
 // over the waves of a workgroup, so it keeps many workgroups on narrow layers at any row count (8192 x 1280 at
 // 512 rows: 20 us against 58 for the best shared-slab shape); the shared-slab kernel wins where rows x columns
 // alone fill the chip.
@@ -101,10 +101,10 @@ Choice choose_mfma32(int M, int K, int N, int batch, bool have_ws = false) {
     double a, b;
   };
   static const Shape shapes[] = {
-      {1, 2, 1, 8, 0.1908, 1.219}, {1, 3, 1, 4, 0.2460, 1.219}, {1, 3, 1, 8, 0.2129, 2.282}, {2, 1, 1, 8, 0.1989, 1.745},
-      {2, 2, 1, 4, 0.2511, 2.911}, {2, 2, 1, 8, 0.2520, 3.133}, {2, 3, 1, 4, 0.3071, 3.938}, {2, 3, 1, 8, 0.3053, 4.916},
-      {4, 3, 1, 4, 0.4728, 6.994}, {2, 1, 8, 1, 0.7597, 3.387}, {2, 2, 8, 1, 1.2742, 4.829}, {2, 3, 8, 1, 1.8469, 5.698},
-      {4, 1, 8, 1, 1.2200, 4.386}, {4, 2, 4, 1, 1.1659, 4.067}, {4, 2, 8, 1, 2.1796, 6.110}, {4, 3, 4, 1, 1.7436, 7.005}};
+      {1, 2, 1, 8, 0.1485, 0.996}, {1, 3, 1, 4, 0.2632, 1.400}, {1, 3, 1, 8, 0.2372, 2.655}, {2, 1, 1, 8, 0.1976, 1.841},
+      {2, 2, 1, 4, 0.1952, 2.407}, {2, 2, 1, 8, 0.2480, 3.315}, {2, 3, 1, 4, 0.2747, 3.685}, {2, 3, 1, 8, 0.3009, 5.090},
+      {4, 3, 1, 4, 0.5151, 7.900}, {2, 1, 8, 1, 0.6954, 3.181}, {2, 2, 8, 1, 1.2726, 4.837}, {2, 3, 8, 1, 1.8081, 5.624},
+      {4, 1, 8, 1, 1.2213, 4.361}, {4, 2, 4, 1, 1.1002, 3.845}, {4, 2, 8, 1, 2.0987, 5.801}, {4, 3, 4, 1, 1.6751, 6.682}};
   Choice best{true, 2, 3, 1, -4};
   double best_cost = 1e300;
   for (const Shape& c : shapes) {
