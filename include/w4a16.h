@@ -210,7 +210,8 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
  * (vllm/model_executor/layers/quantization/awq.py:42-43): there is no reference result to compare with, the tests
  * check against a float64 restatement of the definition above.  Epilogues: W4A16_EPI_NONE, W4A16_EPI_ADD_TO_OUT
  * (bf16 + bf16, rounded once); others return W4A16_E_SHAPE.  mt == 0: the library's launch shape (up to 16 rows
- * the decode kernel where K is a multiple of 128, else the streaming 16x16x32 kernel; beyond 16 rows the 32x32x16
+ * the decode kernel where K is a multiple of 128 (up to 32 rows on narrow layers, as for fp16), else the streaming
+ * 16x16x32 kernel; beyond that the 32x32x16
  * kernels where K is a multiple of 128: private slabs, and beyond 256 rows the shared slab where fp16 takes it);
  * mt > 0: (mt, t, waves) of the streaming kernel as built for bf16; mt == -16: (t, waves) of the decode kernel (up
  * to 16 rows, K a multiple of 128); mt == -36: (t, nw = waves) of the shared-slab 32x32x16 kernel with four row

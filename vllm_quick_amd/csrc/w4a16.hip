@@ -560,6 +560,12 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
   a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
   clear_stale_error();
   if (mt == 0) {
+    // Up to 16 rows (32 on narrow layers) the decode kernel in the launch shape it takes for fp16 (no K split: no
+    // workspace here).
+    if (M <= kDecodeMaxRowsTwo) {
+      const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
+      if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
+    }
     // From 17 rows the 32x32x16 kernel with private slabs (whole 128-k blocks only): one 32-row tile up to 47 rows,
     // two beyond.
     const bool wide_ok = K % 128 == 0 && (long long)a.NT * a.KBS * 1024 < (1LL << 32) &&
@@ -579,11 +585,6 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
       const bool two = M >= 48;
       return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
                            nullptr, 0, true);
-    }
-    // Up to 16 rows the decode kernel in the launch shape it takes for fp16 (no K split: no workspace here).
-    if (M <= kDecodeMaxRowsL2) {
-      const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
-      if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
     }
     choose_bf16(M, K, N, &mt, &t, &waves);
   }

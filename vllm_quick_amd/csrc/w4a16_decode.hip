@@ -455,7 +455,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 #endif
   constexpr size_t ring_lds = (size_t)W * DB * 4096 + (size_t)W * T * 1024;
   const bool two = a.M > kDecodeMaxRowsL2;  // 17-32 rows: two row tiles through the ring, or not at all
-  constexpr bool kTwo = decode_two_row_tiles_built(T, W, DB) && std::is_same<AT, ActF16>::value;
+  constexpr bool kTwo = decode_two_row_tiles_built(T, W, DB);
   if (two && (!kTwo || act || !W4A16_DECODE_RING)) return W4A16_E_SHAPE;
   const bool ring = W4A16_DECODE_RING && !xlds && !two && ring_lds <= 160 * 1024;
   const size_t lds = two ? decode_two_row_tiles_lds(T, W, DB)
