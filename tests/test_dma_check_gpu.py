@@ -67,7 +67,7 @@ def test_no_fragment_overtakes_its_dma_in_any_32x32x16_shape(L, chk, cuda):
         cases.append((torch.from_numpy(x).to(cuda), ops.awq_repack(*[torch.from_numpy(a).to(cuda) for a in (qw, s, qz)])))
     shapes = [("wide", mt, t, kw) for mt, t, kw in L.built_shapes(2)] + \
              [("shared", mt, t, -nw) for mt, t, nw in L.built_shapes(3)]
-    assert len(shapes) == 9 + 7
+    assert len(shapes) == 10 + 7
     for which in ("wide", "shared"):
         assert state(chk, which, set_skip=0) == (0, 0)
     for which, mt, t, kw in shapes:

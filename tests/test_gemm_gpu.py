@@ -182,7 +182,7 @@ def all_built_shapes(L):
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
 def test_every_launch_shape(abi, L, cuda, G):
     CFGS = all_built_shapes(L)
-    assert len(CFGS) == 22 + 7 + 9 + 7  # a shape added to the library is a shape tested here
+    assert len(CFGS) == 22 + 7 + 10 + 7  # a shape added to the library is a shape tested here
     # 6 row tiles (ragged), 25 column tiles (ragged against every T); 10 k-blocks (uneven over 4 or 8 K-groups),
     # and 16 for the LDS-staged shapes with 8 K-groups, which take whole rounds of 8 blocks only
     M, N = 85, 400

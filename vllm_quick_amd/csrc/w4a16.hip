@@ -85,13 +85,15 @@ struct Choice {
 
 // Launch shape of the two 32x32x16 kernels: the built shape with the lowest estimated time,
 //   ceil(workgroups / 256 CUs) x (K / 128 x a + b)   microseconds,
-// a (per 128-k block) and b (prologue, reduction, stores) per shape, fitted by least squares on all sixteen
+// a (per 128-k block) and b (prologue, reduction, stores) per shape, fitted by least squares on all seventeen
 // shapes x 14 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral, 2/4/8-way shards of the
-// benchmark layer) x 48-4096 rows (scripts/exp_shared_sweep.py), then each shape's pair scaled by a common factor
-// of 0.90-1.10 where that lowers the loss of the CHOICE (scripts/fit_chooser.py --tune; whole rounds of 256
-// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.5 %
-// on three sweeps of the current kernels, 33-4096 rows (2.8 % with the constants fitted before the shared-slab
-// kernel's stores were re-arranged); with each layer shape held out of fit and tuning in turn, 0.8 % (worst 13 %).  The private-slab kernel splits K
+// benchmark layer) x 17-4096 rows (scripts/exp_shared_sweep.py), then each shape's pair scaled by a common factor
+// where that lowers the loss of the CHOICE (scripts/fit_chooser.py --tune; whole rounds of 256
+// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.4 %
+// on two sweeps of the current kernels (448 cases); with each layer shape held out of fit and tuning in turn, 0.6 %
+// (worst 17 %).  The 32-row x 32-column private-slab shape <1,1,8> is what narrow layers take up to 64 rows: 128
+// column slices of a 4096-column layer x 2 row blocks fill the chip, where 64-column slices leave half of it idle
+// (11008 x 4096 at 33 / 64 rows 12.1 / 13.6 us against 15.9 / 15.9; 8192 x 1280 at 17-128 rows 8.4-9.5 against 12.0).  The private-slab kernel splits K
 // over the waves of a workgroup, so it keeps many workgroups on narrow layers at any row count (8192 x 1280 at
 // 512 rows: 20 us against 58 for the best shared-slab shape); the shared-slab kernel wins where rows x columns
 // alone fill the chip.
@@ -101,10 +103,11 @@ Choice choose_mfma32(int M, int K, int N, int batch, bool have_ws = false) {
     double a, b;
   };
   static const Shape shapes[] = {
-      {1, 2, 1, 8, 0.1485, 0.996}, {1, 3, 1, 4, 0.2632, 1.400}, {1, 3, 1, 8, 0.2372, 2.655}, {2, 1, 1, 8, 0.1976, 1.841},
-      {2, 2, 1, 4, 0.1952, 2.407}, {2, 2, 1, 8, 0.2480, 3.315}, {2, 3, 1, 4, 0.2747, 3.685}, {2, 3, 1, 8, 0.3009, 5.090},
-      {4, 3, 1, 4, 0.5151, 7.900}, {2, 1, 8, 1, 0.6954, 3.181}, {2, 2, 8, 1, 1.2726, 4.837}, {2, 3, 8, 1, 1.8081, 5.624},
-      {4, 1, 8, 1, 1.2213, 4.361}, {4, 2, 4, 1, 1.1002, 3.845}, {4, 2, 8, 1, 2.0987, 5.801}, {4, 3, 4, 1, 1.6751, 6.682}};
+      {1, 1, 1, 8, 0.1175, 0.866}, {1, 2, 1, 8, 0.1505, 1.336}, {1, 3, 1, 4, 0.2508, 1.701}, {1, 3, 1, 8, 0.2334, 3.177},
+      {2, 1, 1, 8, 0.1846, 2.179}, {2, 2, 1, 4, 0.2058, 3.005}, {2, 2, 1, 8, 0.2260, 3.757}, {2, 3, 1, 4, 0.2880, 4.288},
+      {2, 3, 1, 8, 0.2787, 5.340}, {4, 3, 1, 4, 0.4897, 7.834}, {2, 1, 8, 1, 0.6417, 2.984}, {2, 2, 8, 1, 1.2501, 4.449},
+      {2, 3, 8, 1, 1.7864, 5.184}, {4, 1, 8, 1, 1.1968, 3.974}, {4, 2, 4, 1, 1.1510, 3.847}, {4, 2, 8, 1, 2.2194, 5.541},
+      {4, 3, 4, 1, 1.6579, 6.125}};
   Choice best{true, 2, 3, 1, -4};
   double best_cost = 1e300;
   for (const Shape& c : shapes) {
@@ -261,15 +264,6 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false, bool hav
 // shape chosen (4-7 % faster at 5-16 rows, 8-20 % at up to 4).  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
 // over K as well.
 Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool have_ws) {
-  // 17-32 rows: the decode kernel with two 16-row tiles, in the launch shape it takes at 16 rows, where that shape is
-  // built for two row tiles (plain GEMM).
-  if (M > kDecodeMaxRowsL2 && M <= kDecodeMaxRowsTwo && !act && K % 128 == 0) {
-    Choice c16 = choose_with_decode(kDecodeMaxRowsL2, K, N, G, batch, act, false);
-    if (c16.splits > 0 && decode_two_row_tiles_built(c16.t, c16.a, 1)) {
-      c16.splits = 1;
-      return c16;
-    }
-  }
   Choice c = choose_cfg(M, K, N, batch, act, have_ws);
   if (c.tiled || c.mt != 1 || M > kDecodeMaxRowsL2) return c;
   GemmArgs probe;
@@ -560,12 +554,6 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
   a.add_out = epilogue == W4A16_EPI_ADD_TO_OUT;
   clear_stale_error();
   if (mt == 0) {
-    // Up to 16 rows (32 on narrow layers) the decode kernel in the launch shape it takes for fp16 (no K split: no
-    // workspace here).
-    if (M <= kDecodeMaxRowsTwo) {
-      const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
-      if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
-    }
     // From 17 rows the 32x32x16 kernel with private slabs (whole 128-k blocks only): one 32-row tile up to 47 rows,
     // two beyond.
     const bool wide_ok = K % 128 == 0 && (long long)a.NT * a.KBS * 1024 < (1LL << 32) &&
@@ -586,6 +574,11 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
       return dispatch_wide(a, two ? 2 : 1, two ? 3 : 2, two ? 4 : 8, static_cast<hipStream_t>(stream), 1, false, 1,
                            nullptr, 0, true);
     }
+    // Up to 16 rows the decode kernel in the launch shape it takes for fp16 (no K split: no workspace here).
+    if (M <= kDecodeMaxRowsL2) {
+      const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
+      if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
+    }
     choose_bf16(M, K, N, &mt, &t, &waves);
   }
   if (mt < 0) {
@@ -605,7 +598,7 @@ int w4a16_built_shape_bf16(int i, int* shape) {
 #define X(MT_, T_, W_) {MT_, T_, W_},
       W4A16_FOR_EACH_BF16(X)
 #undef X
-      {-2, 3, 4}, {-1, 2, 8}, {-4, 3, 4}, {-1, 3, 4}, {-2, 2, 4},  // the private-slab 32x32x16 kernel (wide_bf16_built)
+      {-2, 3, 4}, {-1, 2, 8}, {-4, 3, 4}, {-1, 3, 4}, {-2, 2, 4}, {-1, 1, 8},  // the private-slab 32x32x16 kernel (wide_bf16_built)
 #define X(T_, W_) {kBf16DecodeTag, T_, W_},
       W4A16_FOR_EACH_DECODE(X)  // the decode kernel
 #undef X

@@ -505,7 +505,7 @@ inline int row_block_magic(long long items, int m_blocks, int panel_rows) {
 // (mt, t, kw) of the 32x32x16 kernel with private slabs: mt, t in 32-row / 32-column tiles
 #ifndef W4A16_FOR_EACH_WIDE  // (kernel experiments build a single shape: -D'W4A16_FOR_EACH_WIDE(X)=X(2,3,4)')
 #define W4A16_FOR_EACH_WIDE(X) \
-  X(2, 3, 8) X(2, 2, 8) X(2, 1, 8) X(1, 3, 8) X(1, 2, 8) X(2, 3, 4) X(2, 2, 4) X(1, 3, 4) X(4, 3, 4)
+  X(2, 3, 8) X(2, 2, 8) X(2, 1, 8) X(1, 3, 8) X(1, 2, 8) X(2, 3, 4) X(2, 2, 4) X(1, 3, 4) X(4, 3, 4) X(1, 1, 8)
 #endif
 // Slices (1 KiB: 4 accumulator registers x 64 lanes) per owner wave in the private-slab kernel's final exchange, and
 // the workspace a K split over workgroups needs: the ticket region, then 4 owners x that many KiB per output tile
@@ -519,7 +519,7 @@ constexpr bool wide_double_slab(int mt, int kw) { return W4A16_WIDE_DBL && mt ==
 // private-slab shapes also built for bf16 activations (17 rows and more)
 constexpr bool wide_bf16_built(int mt, int t, int kw) {
   return (mt == 2 && t == 3 && kw == 4) || (mt == 1 && t == 2 && kw == 8) || (mt == 4 && t == 3 && kw == 4) ||
-         (mt == 1 && t == 3 && kw == 4) || (mt == 2 && t == 2 && kw == 4);
+         (mt == 1 && t == 3 && kw == 4) || (mt == 2 && t == 2 && kw == 4) || (mt == 1 && t == 1 && kw == 8);
 }
 constexpr int wide_slices_per_owner(int mt, int t, bool act) { return act ? ((t * mt + 1) / 2) * 2 : t * mt; }
 inline size_t wide_ws_bytes(long long tiles, int splits, int mt, int t, bool act);
@@ -535,25 +535,13 @@ constexpr bool wide_shared_bf16_built(int mt, int t, int nw) {
 
 // ---- decode kernel (up to 4 rows) ----
 constexpr int kDecodeMaxRows = 4;    // with LDS staging, the compact reduction and the optional K split
-constexpr int kDecodeMaxRowsL2 = 16;  // one 16-row tile: through the LDS ring or with fragments straight from L2 (no K split)
-constexpr int kDecodeMaxRowsTwo = 32;  // two 16-row tiles through the LDS ring (plain fp16 GEMM, one block in flight)
-// Two row tiles: each (tile, row tile) is summed by a wave of its own; a wave parks its partial tiles in its own 8-KiB
-// ring slot where they fit (up to 4 column tiles), else behind the ring.
-constexpr size_t decode_two_row_tiles_lds(int t, int waves, int db) {
-  return (size_t)waves * db * 8192 + (2 * t * 1024 <= db * 8192 ? 0 : (size_t)waves * 2 * t * 1024);
-}
-// Built where it is ahead of the 32x32x16 kernel: one or two column tiles x 16 waves (narrow layers and long K: 4096 x
-// 4096 at 17 / 32 rows 6.5 / 7.6 us against 7.9 / 8.2, 11008 x 4096 12.6 / 15.7 against 15.9 / 15.9, 14336 x 4096 15.7 /
-// 19.1 against 20.4 / 24.1); with three tiles x 16 waves it runs out of registers (128 per lane) and loses.
-constexpr bool decode_two_row_tiles_built(int t, int waves, int db) {
-  return db == 1 && waves == 16 && t <= 2 && decode_two_row_tiles_lds(t, waves, db) <= 160 * 1024;
-}
+constexpr int kDecodeMaxRowsL2 = 16;  // with fragments straight from L2 (no K split)
 constexpr int kMaxSplits = 8;
 
 // What the decode kernel's addressing admits: whole 128-k blocks, 32-bit byte offsets, and a group size whose
 // group index is a shift or one multiply away from the block index.
 inline bool decode_ok(const GemmArgs& a) {
-  if (a.M > kDecodeMaxRowsTwo || a.K % 128 || (long long)a.M * a.K * 2 >= (1LL << 31)) return false;
+  if (a.M > kDecodeMaxRowsL2 || a.K % 128 || (long long)a.M * a.K * 2 >= (1LL << 31)) return false;
   if (!(a.G == 32 || a.G == 64 || (a.G % 128 == 0 && a.G / 128 <= 64))) return false;
   if (a.KB >= 1024) return false;
   if ((long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.NT * a.NG * 64 >= (1LL << 31)) return false;
