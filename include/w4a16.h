@@ -210,7 +210,8 @@ int w4a16_gemm_packed_f16_ex(const void* x, long long x_batch_stride, const void
  * (vllm/model_executor/layers/quantization/awq.py:42-43): there is no reference result to compare with, the tests
  * check against a float64 restatement of the definition above.  Epilogues: W4A16_EPI_NONE, W4A16_EPI_ADD_TO_OUT
  * (bf16 + bf16, rounded once); others return W4A16_E_SHAPE.  mt == 0: the library's launch shape (up to 16 rows
- * the decode kernel where K is a multiple of 128, else the streaming 16x16x32 kernel; beyond 16 rows the 32x32x16
+ * the decode kernel where K is a multiple of 128 (up to 32 rows on narrow layers, as for fp16), else the streaming
+ * 16x16x32 kernel; beyond that the 32x32x16
  * kernels where K is a multiple of 128: private slabs, and beyond 256 rows the shared slab where fp16 takes it);
  * mt > 0: (mt, t, waves) of the streaming kernel as built for bf16; mt == -16: (t, waves) of the decode kernel (up
  * to 16 rows, K a multiple of 128); mt == -36: (t, nw = waves) of the shared-slab 32x32x16 kernel with four row
@@ -240,12 +241,14 @@ int w4a16_gemm_packed_f16_masked(const void* x, long long x_batch_stride, const 
                                  int epilogue, const void* problem_mask, int active_hint, void* stream);
 
 /*
- * The decode kernel (up to 16 rows; the K split up to 4 rows and 4 tiles or tile pairs per workgroup) with an
+ * The decode kernel (up to 16 rows, and 17-32 rows of the plain GEMM with t = 1 and 16 waves; the K split up to 4
+ * rows and 4 tiles or tile pairs per workgroup) with an
  * explicit launch shape, for tuning and tests;
  * batching and epilogues as for w4a16_gemm_packed_f16_ex.  A workgroup owns t 16-column tiles (fused activation: t / 2 gate + t / 2 up
  * tiles) for the rows; its `waves` wavefronts split the workgroup's share of K by 128-k blocks, each keeps
  * `depth` blocks of weights in flight (1 or 2; 0 = the library's choice) and, up to 4 rows, stages its activations
- * in a private piece of LDS (5-16 rows: fragments straight from L2).  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
+ * in a private piece of LDS (5-32 rows: a ring of LDS slots filled block by block, or fragments straight from L2 where
+ * the ring does not fit).  splits > 1 divides K over that many workgroups per output slot: each leaves fp32 partial sums in
  * `workspace`, and the one that arrives last adds them in split order, so the result does not depend on timing.
  * `workspace` (16-byte aligned; may be NULL when splits == 1) must hold w4a16_decode_workspace_bytes(...) bytes,
  * zero before its first use: the kernels return every counter they touch to zero, so one buffer serves any
@@ -323,7 +326,7 @@ int w4a16_gemm_packed_f16_decode_static(const void* x, long long x_batch_stride,
  *                MFMA32      (mt, t, splits, kw)    32-row / 32-column tiles, private slabs per wavefront
  *                                                   (splits = 1 unless a workspace lets K be split over workgroups)
  *                MFMA32_SHARED (mt, t, nw, 1)       32-row / 32-column tiles, one slab per workgroup
- *                DECODE      (1, t, waves, splits)  up to 16 rows
+ *                DECODE      (1, t, waves, splits)  up to 16 rows (32 with t = 1 and 16 waves)
  * w4a16_launch_shape takes no group size: it answers for a group size the decode kernel admits (32, 64 or a
  * multiple of 128, i.e. every AWQ checkpoint in use); for another multiple of 32 the launches it reports as
  * DECODE are made by the streaming kernel with the same (t, waves).  w4a16_launch_shape_ws takes the group size.

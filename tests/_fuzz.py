@@ -61,8 +61,8 @@ def one_case(rng, modes=MODES, large=False):
     if mode == "wide_split":  # whole 128-k blocks
         M = int(rng.integers(1, 200))
         K = 128 * int(rng.integers(1, 24)) if G <= 128 else 256 * int(rng.integers(1, 12))
-    if mode == "decode":  # the decode kernel with a forced shape: up to 16 rows, whole 128-k blocks
-        M = int(rng.integers(1, 17))
+    if mode == "decode":  # the decode kernel with a forced shape: up to 16 rows (32 with two row tiles), whole 128-k blocks
+        M = int(rng.integers(1, 33))
         K = 128 * int(rng.integers(1, 40)) if G <= 128 else G * int(rng.integers(1, 20))
         N = 16 * int(rng.integers(1, 60))
     x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=int(rng.integers(1 << 30)))
@@ -102,6 +102,8 @@ def one_case(rng, modes=MODES, large=False):
         elif mode == "decode":
             want, exact = orc.gemm_faithful(x, qw, s, qz).astype(np.float64), orc.gemm_exact(x, qw, s, qz)
             shapes = _lib.built_shapes(4)
+            if M > 16:  # two row tiles: one column tile x 16 waves
+                shapes = [c for c in shapes if c[1] == 16 and c[0] == 1]
             tt, ww, _ = shapes[rng.integers(len(shapes))]
             splits = int(rng.integers(1, 5)) if M <= 4 and tt <= 4 else 1
             cfg = ("decode", int(tt), int(ww), splits, int(rng.integers(0, 3)))

@@ -51,7 +51,13 @@ DECODE_TAG = -16  # first entry of a built shape that names the decode kernel (u
 def refused(cfg, M, K):
     """Launch shapes that do not take the problem: the 32x32x16 and decode kernels want whole 128-k blocks, the decode
     kernel up to 16 rows.  (-36, t, nw) names the shared-slab 32x32x16 kernel: whole blocks, any row count.)"""
-    return cfg is not None and cfg[0] < 0 and (K % 128 != 0 or (cfg[0] == DECODE_TAG and M > 16))
+    if cfg is None or cfg[0] >= 0:
+        return False
+    if K % 128 != 0:
+        return True
+    if cfg[0] == DECODE_TAG:  # up to 16 rows; 17-32 with one column tile x 16 waves
+        return M > 32 or (M > 16 and not (cfg[2] == 16 and cfg[1] == 1))
+    return False
 
 
 def bf16_tensor(bits, cuda):
@@ -139,7 +145,7 @@ def test_every_built_shape_and_odd_sizes(L, ops, cuda):
     16 per workgroup, every built shape at 5, 16, 40 and 150 rows."""
     N, G = 328, 32
     for K in (1056, 1280):
-        for M in (5, 16, 40, 150):
+        for M in (5, 16, 27, 40, 150):
             xb, qw, s, qz = make(M, K, N, G, seed=7 + M + K)
             packed = ops.awq_repack(dev_t(qw, cuda), dev_t(s, cuda), dev_t(qz, cuda))
             for cfg in built_shapes(L):

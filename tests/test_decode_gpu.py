@@ -110,6 +110,33 @@ def test_every_decode_shape(L, ops, cuda, G):
     assert int(ws[:65536].view(torch.int32).abs().max().item()) == 0
 
 
+@pytest.mark.parametrize("G", [32, 64, 128])
+def test_two_row_tiles_17_to_32_rows(L, ops, cuda, G):
+    """17-32 rows: two 16-row tiles through the LDS ring, one column tile x 16 waves; ragged columns, k-blocks
+    uneven over the waves (and enough of them for the oldest waves to take a block from the youngest), bias and
+    add-to-out, whatever depth is asked for."""
+    N = 400
+    for K in (1280, 2816, 4736):
+        for M in (17, 23, 32):
+            x, qw, s, qz = orc.make_inputs(M, K, N, G, seed=G + K + M)
+            want, exact = orc.gemm_faithful(x, qw, s, qz), orc.gemm_exact(x, qw, s, qz)
+            bias = (np.random.default_rng(M).standard_normal(N) * 0.2).astype(np.float16)
+            tx, tb = dev_t(x, cuda), dev_t(bias, cuda)
+            packed = ops.awq_repack(*[dev_t(a, cuda) for a in (qw, s, qz)])
+            for t, waves in ((1, 16), ):
+                what = f"G={G} K={K} M={M} t={t}"
+                y = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None)
+                assert_parity(y.cpu().numpy(), want, exact, what)
+                assert torch.equal(launch(L, cuda, tx, packed, K, N, G, t, waves, 2, 1, None), y), what
+                yb = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None, bias=tb)
+                assert torch.equal(yb, y + tb), what
+                res = dev_t((np.random.default_rng(K).standard_normal((M, N))).astype(np.float16), cuda)
+                ya = launch(L, cuda, tx, packed, K, N, G, t, waves, 0, 1, None, epilogue=2, out=res.clone())
+                assert torch.equal(ya, res + y), what
+    # the library takes this path on a narrow layer
+    assert "gemm_decode_kernel<1,16>" in L.launch_shape(24, 4096, 4096)
+
+
 def test_split_launches_repeat_bit_for_bit_and_share_a_workspace(L, ops, cuda):
     """One workspace, never cleared again, serves launches of different shapes back to back, and a split launch
     returns the same bits however its workgroups are scheduled."""
@@ -151,7 +178,12 @@ def test_workspace_errors_and_sizes(L, ops, cuda):
     launch(L, cuda, x5, packed, K, N, G, 1, 8, 0, 2, ws_ok := torch.zeros(need, dtype=torch.uint8, device=cuda),
            expect=-5)                                                      # the K split takes up to 4 rows
     x17 = dev_t(orc.make_inputs(17, K, N, G, seed=6)[0], cuda)
-    launch(L, cuda, x17, packed, K, N, G, 1, 8, 0, 1, None, expect=-5)   # more than 16 rows
+    launch(L, cuda, x17, packed, K, N, G, 1, 8, 0, 1, None, expect=-5)   # more than 16 rows: 1 tile x 16 waves only
+    launch(L, cuda, x17, packed, K, N, G, 3, 16, 0, 1, None, expect=-5)
+    launch(L, cuda, x17, packed, K, N, G, 2, 16, 0, 1, None, expect=-5)
+    launch(L, cuda, x17, packed, K, N, G, 1, 16, 0, 1, None, epilogue=1, expect=-5)  # ... and the plain GEMM only
+    x33 = dev_t(orc.make_inputs(33, K, N, G, seed=6)[0], cuda)
+    launch(L, cuda, x33, packed, K, N, G, 1, 16, 0, 1, None, expect=-5)  # more than 32 rows
     assert L.lib.w4a16_strerror(-9).startswith(b"workspace too small")
     # splits beyond the k-blocks are trimmed, not an error: 8 blocks over "8 splits" of one block each
     ws = ops.gemm_workspace(cuda, L.lib.w4a16_decode_workspace_bytes(K, N, 1, 0, 1, 8, 8))

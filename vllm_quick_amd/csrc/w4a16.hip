@@ -264,6 +264,15 @@ Choice choose_cfg(int M, int K, int N, int batch = 1, bool act = false, bool hav
 // shape chosen (4-7 % faster at 5-16 rows, 8-20 % at up to 4).  With a workspace a launch that would leave most CUs idle (few column tiles, long K) is split
 // over K as well.
 Choice choose_with_decode(int M, int K, int N, int G, int batch, bool act, bool have_ws) {
+  // 17-32 rows: the decode kernel with two 16-row tiles, in the launch shape it takes at 16 rows, where that shape is
+  // built for two row tiles (plain GEMM on layers of up to 256 column tiles).
+  if (M > kDecodeMaxRowsL2 && M <= kDecodeMaxRowsTwo && !act && K % 128 == 0) {
+    Choice c16 = choose_with_decode(kDecodeMaxRowsL2, K, N, G, batch, act, false);
+    if (c16.splits > 0 && decode_two_row_tiles_built(c16.t, c16.a, 1)) {
+      c16.splits = 1;
+      return c16;
+    }
+  }
   Choice c = choose_cfg(M, K, N, batch, act, have_ws);
   if (c.tiled || c.mt != 1 || M > kDecodeMaxRowsL2) return c;
   GemmArgs probe;
@@ -575,7 +584,7 @@ int w4a16_gemm_packed_bf16(const void* x, const void* packed_w, const void* pack
                            nullptr, 0, true);
     }
     // Up to 16 rows the decode kernel in the launch shape it takes for fp16 (no K split: no workspace here).
-    if (M <= kDecodeMaxRowsL2) {
+    if (M <= kDecodeMaxRowsTwo) {
       const Choice c = choose_with_decode(M, K, N, G, 1, false, false);
       if (c.splits > 0) return dispatch_decode(a, c.t, c.a, static_cast<hipStream_t>(stream), 1, false, 1, nullptr, 0, 0, true);
     }

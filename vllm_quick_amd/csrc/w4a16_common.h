@@ -535,13 +535,26 @@ constexpr bool wide_shared_bf16_built(int mt, int t, int nw) {
 
 // ---- decode kernel (up to 4 rows) ----
 constexpr int kDecodeMaxRows = 4;    // with LDS staging, the compact reduction and the optional K split
-constexpr int kDecodeMaxRowsL2 = 16;  // with fragments straight from L2 (no K split)
+constexpr int kDecodeMaxRowsL2 = 16;  // one 16-row tile: through the LDS ring or with fragments straight from L2 (no K split)
+constexpr int kDecodeMaxRowsTwo = 32;  // two 16-row tiles through the LDS ring (plain GEMM, one block in flight)
+// Two row tiles: each (tile, row tile) is summed by a wave of its own; a wave parks its partial tiles in its own 8-KiB
+// ring slot where they fit (up to 4 column tiles), else behind the ring.
+constexpr size_t decode_two_row_tiles_lds(int t, int waves, int db) {
+  return (size_t)waves * db * 8192 + (2 * t * 1024 <= db * 8192 ? 0 : (size_t)waves * 2 * t * 1024);
+}
+// Built where it is ahead of the 32x32x16 kernel with weights coming from HBM: one column tile x 16 waves, i.e. layers
+// of up to 256 tiles (4096 columns), which it covers with twice the workgroups of the 32-column shape <1,1,8>
+// (4096 x 4096 at 17 / 32 rows 6.15 / 7.2 us against 6.8 / 7.7, 11008 x 4096 12.2 / 15.4 against 13.8 / 17.9); with two
+// tiles it draws level with <1,1,8>, with three x 16 waves it runs out of registers (128 per lane).
+constexpr bool decode_two_row_tiles_built(int t, int waves, int db) {
+  return db == 1 && waves == 16 && t == 1 && decode_two_row_tiles_lds(t, waves, db) <= 160 * 1024;
+}
 constexpr int kMaxSplits = 8;
 
 // What the decode kernel's addressing admits: whole 128-k blocks, 32-bit byte offsets, and a group size whose
 // group index is a shift or one multiply away from the block index.
 inline bool decode_ok(const GemmArgs& a) {
-  if (a.M > kDecodeMaxRowsL2 || a.K % 128 || (long long)a.M * a.K * 2 >= (1LL << 31)) return false;
+  if (a.M > kDecodeMaxRowsTwo || a.K % 128 || (long long)a.M * a.K * 2 >= (1LL << 31)) return false;
   if (!(a.G == 32 || a.G == 64 || (a.G % 128 == 0 && a.G / 128 <= 64))) return false;
   if (a.KB >= 1024) return false;
   if ((long long)a.NT * a.KBS * 1024 >= (1LL << 32) || (long long)a.NT * a.NG * 64 >= (1LL << 31)) return false;

@@ -37,10 +37,15 @@ namespace {
 // cache lines, where a fragment load touches 16 separate 64-byte pieces; rows past M - 1 repeat the last row), chunk
 // c of row r at 16-byte position c ^ r of the row, so that the ds_read_b128 fragment reads are conflict-free; the
 // slot of block b is refilled for block b + DB right after the block's first unit has consumed its fragments.
+// 3: 17-32 rows, the ring with two 16-row tiles (slots of 8 KiB, eight DMA instructions per block): a converted weight
+// fragment feeds two matrix instructions.
 template <int T, int W, int DB, int SZS, bool ACT = false, int XM = 1, class AT = ActF16>
 __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, const DecodeArgs e) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (and has no buffer-resource type)
-  constexpr bool XLDS = XM == 1, XRING = XM == 2;
+  constexpr bool XLDS = XM == 1, XRING = XM >= 2;
+  constexpr int MT = XM == 3 ? 2 : 1;  // 16-row tiles
+  static_assert(MT == 1 || !ACT, "two row tiles: plain GEMM only");
+  constexpr int SLOT = MT * 4096;      // bytes of a ring slot
   typedef typename AT::elem elem;
   typedef typename AT::x4 ex4;
   typedef typename AT::x8 ex8;
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   // LDS-DMA of one block's activations (1 KiB of the wave's private LDS): lane -> row lane >> 4 (rows past
   // M - 1 repeat it), 16-byte position lane & 15 of the row, which holds chunk (lane & 15) ^ 4 (lane >> 4)
   const uint32_t xlane = ((uint32_t)min(kq, a.M - 1) * a.K + ((n16 ^ (4 * kq)) * 8)) * 2u;
-  const int xwave = XRING ? w * (DB * 4096) : w * nb_max * 1024;
+  const int xwave = XRING ? w * (DB * SLOT) : w * nb_max * 1024;
   // B fragment of k-step j: row min(n16, M - 1) (the matrix instruction's columns past M - 1 are never stored),
   // chunk 4 j + kq
   int xrd[4];
@@ -122,26 +127,29 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
       xrd[j] = XRING ? xwave + n16 * 256 + (((4 * j + kq) ^ n16) << 4) : xwave + rr * 256 + ((4 * (j ^ rr) + kq) << 4);
   }
   // ring: DMA i of a block fills rows 4 i .. 4 i + 3: lane -> row 4 i + (lane >> 4), position lane & 15
-  uint32_t xring[XRING ? 4 : 1];
+  constexpr int XD = 4 * MT;  // DMA instructions per block
+  uint32_t xring[XRING ? XD : 1];
   if constexpr (XRING) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XD; ++i) {
       const int row = 4 * i + kq;
-      xring[i] = ((uint32_t)min(row, a.M - 1) * a.K + ((n16 ^ row) * 8)) * 2u;
+      xring[i] = ((uint32_t)min(row, a.M - 1) * a.K + ((n16 ^ (row & 15)) * 8)) * 2u;
     }
   }
   auto dma_ring = [&](int kb, int slot) {
     if constexpr (XRING) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + slot * 4096 + i * 1024), 16, xring[i],
+      for (int i = 0; i < XD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr)(smem_raw + xwave + slot * SLOT + i * 1024), 16, xring[i],
                                                  kb * 256, 0, 0);
     }
   };
 
-  f32x4 acc[T];
+  f32x4 acc[T][MT];
 #pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const DqConst dqc = make_dq_const();
 
   struct Unit {
@@ -157,42 +165,46 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
     }
     d.q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wlane, wbase[t] + kb * 1024, 2));  // nt
   };
-  auto compute_unit = [&](int t, const Unit& d, const ex8 (&xf)[4]) {
+  auto compute_unit = [&](int t, const Unit& d, const ex8 (&xf)[4][MT]) {
     typename AT::consts c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j % SZS == 0) c = AT::expand(d.sz[j / SZS]);
       const ex8 af = AT::dequant(d.q[j], c, dqc);
-      acc[t] = AT::mfma16(af, xf[j], acc[t]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = AT::mfma16(af, xf[j][mt], acc[t][mt]);
     }
   };
   // Without LDS staging: the B fragments of a block (row min(n16, M - 1), k = 32 j + 8 kq .. + 7), 4 loads
   const uint32_t xfrag_lane = ((uint32_t)min(n16, a.M - 1) * a.K + kq * 8) * 2u;
-  auto load_x = [&](int kb, ex8 (&xf)[4]) {
+  auto load_x = [&](int kb, ex8 (&xf)[4][MT]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      xf[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, xfrag_lane, (kb * 128 + j * 32) * 2, 0));
+      xf[j][0] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, xfrag_lane, (kb * 128 + j * 32) * 2, 0));
   };
   // One block from the registers `u`; with REFILL each unit's registers are asked to fetch the same tile's unit
   // of block kb_refill as soon as the unit is consumed; with XNEXT (fragments from L2 only) the next block's
   // fragments are requested into `xnext` first.  (Compile-time flags: a load under a run-time branch makes the
   // compiler wait for every load in flight.)
-  auto step = [&](auto refill_, auto xnext_, int bi, Unit (&u)[T], ex8 (&xcur)[4], ex8 (&xnext)[4], int kb_refill,
+  auto step = [&](auto refill_, auto xnext_, int bi, Unit (&u)[T], ex8 (&xcur)[4][MT], ex8 (&xnext)[4][MT], int kb_refill,
                   int kb_xnext) {
     constexpr bool REFILL = decltype(refill_)::value != 0;
     constexpr bool XNEXT = decltype(xnext_)::value != 0;
-    ex8 xl[4];
+    ex8 xl[4][MT];
     if constexpr (XLDS) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + bi * 1024);
+      for (int j = 0; j < 4; ++j) xl[j][0] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + bi * 1024);
     } else if constexpr (XRING) {
       // The slot's DMA was issued ahead of this block's weights; younger than it are those T * UL loads and, with two
       // blocks in flight and a block after this one, that block's DMA and weights.  (The counter has 6 bits.)
-      constexpr int YOUNGER = (DB == 2 && XNEXT) ? 2 * T * UL + 4 : T * UL;
+      constexpr int YOUNGER = (DB == 2 && XNEXT) ? 2 * T * UL + XD : T * UL;
       wait_vmcnt<(YOUNGER < 63 ? YOUNGER : 63)>();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xl[j] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + (bi % DB) * 4096);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)  // (row 16 mt + n16 lies 4096 bytes on, swizzled alike)
+          xl[j][mt] = *reinterpret_cast<const ex8*>(smem_raw + xrd[j] + (bi % DB) * SLOT + mt * 4096);
     } else if constexpr (XNEXT) {
       load_x(kb_xnext, xnext);
       __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   };
 
   if (nblk > 0) {
-    ex8 xa[4], xb[4];
+    ex8 xa[4][MT], xb[4][MT];
     if constexpr (XLDS) {
       // activations first: they come from L2 and are back before the weights
       for (int bi = 0; bi < nblk; ++bi)
@@ -290,28 +302,35 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   // anything that is stored; they park their 16 bytes as [wave][tile][token][lane >> 4] and the first wave
   // sums the W partials of every (tile, token, 4-column group), one lane each.
   if constexpr (!XLDS) {
-    // 5-16 rows: whole partial tiles (1 KiB per wave and tile), wave ti sums tile ti (and its up-half twin)
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (XRING ? W * DB * 4096 : 0));  // (behind the ring: other waves may still read theirs)
+    // 5-32 rows: whole partial tiles (1 KiB per wave and tile), wave ti sums tile ti (and its up-half twin).  With
+    // two row tiles a wave parks its partial tiles in its OWN ring slots where they fit (nobody else touches those, so
+    // the ring and the parked tiles share LDS); else behind the ring, since other waves may still be reading theirs.
+    constexpr int TMT = T * MT;                                      // partial tiles per wave: (t, mt) -> t MT + mt
+    constexpr bool OWN = MT == 2 && TMT * 1024 <= DB * SLOT;
+    constexpr int PSTRIDE = OWN ? DB * SLOT / 16 : TMT * 64;          // f32x4 between two waves' parked tiles
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw + ((XRING && !OWN) ? W * DB * SLOT : 0));
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[(w * T + t) * 64 + lane] = acc[t];
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) red[w * PSTRIDE + (t * MT + mt) * 64 + lane] = acc[t][mt];
     __syncthreads();
     STAMP(11);
-    if (w >= H) return;
-    const int ti = w;
-    f32x4 v = red[ti * 64 + lane], vu = v;
+    if (w >= H * MT) return;
+    const int ti = w / MT, rt = w % MT;  // column tile, row tile
+    f32x4 v = red[w * 64 + lane], vu = v;
 #pragma unroll
-    for (int s = 1; s < W; ++s) v += red[(s * T + ti) * 64 + lane];
+    for (int s = 1; s < W; ++s) v += red[s * PSTRIDE + w * 64 + lane];
     if constexpr (ACT) {
       vu = red[(ti + H) * 64 + lane];
 #pragma unroll
-      for (int s = 1; s < W; ++s) vu += red[(s * T + ti + H) * 64 + lane];
+      for (int s = 1; s < W; ++s) vu += red[s * PSTRIDE + (ti + H) * 64 + lane];
     }
     auto finish = [&](f32x4 r, int n_bias) {
       ex4 h = AT::round(r);
       if (a.bias != nullptr) h = AT::add(h, *reinterpret_cast<const ex4*>(reinterpret_cast<const elem*>(a.bias) + n_bias));
       return h;
     };
-    const int nt = nt0 + ti, n = nt * 16 + kq * 4, tok = n16;
+    const int nt = nt0 + ti, n = nt * 16 + kq * 4, tok = 16 * rt + n16;
     if (tok >= a.M) return;
     if constexpr (ACT) {
       const int NH = a.N / 2;
@@ -332,7 +351,7 @@ __global__ void __launch_bounds__(64 * W) gemm_decode_kernel(const GemmArgs ga, 
   unsigned* const tickets = e.tickets;
   if (n16 < 4) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[((w * T + t) * 4 + n16) * 4 + kq] = acc[t];
+    for (int t = 0; t < T; ++t) red[((w * T + t) * 4 + n16) * 4 + kq] = acc[t][0];
   }
   __syncthreads();
   STAMP(11);
@@ -435,8 +454,12 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
 #define W4A16_DECODE_RING 1
 #endif
   constexpr size_t ring_lds = (size_t)W * DB * 4096 + (size_t)W * T * 1024;
-  const bool ring = W4A16_DECODE_RING && !xlds && ring_lds <= 160 * 1024;
-  const size_t lds = ring ? ring_lds : decode_lds_bytes(T, W, nb_max + 1, a.M, a.G);  // (+ 1: a wave may take a block from another)
+  const bool two = a.M > kDecodeMaxRowsL2;  // 17-32 rows: two row tiles through the ring, or not at all
+  constexpr bool kTwo = decode_two_row_tiles_built(T, W, DB);
+  if (two && (!kTwo || act || !W4A16_DECODE_RING)) return W4A16_E_SHAPE;
+  const bool ring = W4A16_DECODE_RING && !xlds && !two && ring_lds <= 160 * 1024;
+  const size_t lds = two ? decode_two_row_tiles_lds(T, W, DB)
+                         : ring ? ring_lds : decode_lds_bytes(T, W, nb_max + 1, a.M, a.G);  // (+ 1: a wave may take a block from another)
   if (lds > 160 * 1024) return W4A16_E_SHAPE;
   const int tiles = act ? a.NT / 2 : a.NT, per_wg = act ? T / 2 : T;
   const int gx = ceil_div(tiles, per_wg);
@@ -460,6 +483,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
   void (*kern)(const GemmArgs, const DecodeArgs) = nullptr;
   const int szs = a.G % 128 == 0 ? 4 : a.G == 64 ? 2 : 1;
   constexpr int kRingXm = ring_lds <= 160 * 1024 ? 2 : 0;  // (no ring instantiation for shapes it never fits)
+  constexpr int kTwoXm = kTwo ? 3 : 0;
 #define W4A16_PICK(SZS_)                                                                         \
   if (szs == SZS_) {                                                                             \
     if (act) {                                                                                   \
@@ -468,6 +492,7 @@ int launch_decode(const GemmArgs& a, hipStream_t s, int batch, bool act, int spl
                                         : gemm_decode_kernel<T, W, DB, SZS_, true, 0, AT>;       \
     } else {                                                                                     \
       if constexpr (kPlain) kern = xlds ? gemm_decode_kernel<T, W, DB, SZS_, false, 1, AT>          \
+                                   : two  ? gemm_decode_kernel<T, W, DB, SZS_, false, kTwoXm, AT>   \
                                    : ring ? gemm_decode_kernel<T, W, DB, SZS_, false, kRingXm, AT>  \
                                           : gemm_decode_kernel<T, W, DB, SZS_, false, 0, AT>;       \
     }                                                                                            \
@@ -503,6 +528,7 @@ int dispatch_decode(const GemmArgs& a, int t, int waves, hipStream_t s, int batc
   // 4 x 8: 8.5 against 9.5).
   // 2 tiles x 16 waves stay at two blocks from 5 rows on (fragments from L2: 8192 x 8192 at 8 rows 9.6 against
   // 10.1) and from K = 12800 on (13824 x 5120: 10.6 against 10.9).
+  if (a.M > kDecodeMaxRowsL2) depth = 1;  // two row tiles: built with one block in flight
   if (depth == 0) {
     const int streams = t * waves;
     depth = (streams < 24 || (streams < 32 && a.K >= 6144) ||

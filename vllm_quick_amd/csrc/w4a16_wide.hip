@@ -465,9 +465,10 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
   #ifndef W4A16_DIRECT8
 #define W4A16_DIRECT8 1
 #endif
-  constexpr bool DIRECT8 = W4A16_DIRECT8 && KW == 8 && !ACT && NSL % 8 == 0 && 56 * (NSL / 8) <= 160;
+  // (Four slices, one 32 x 32 tile: waves 0-3 own one each, all eight send.)
+  constexpr bool DIRECT8 = W4A16_DIRECT8 && KW == 8 && !ACT && (NSL % 8 == 0 || NSL == 4) && 56 * ((NSL + 7) / 8) <= 160;
   if constexpr (DIRECT8) {
-    constexpr int P8 = NSL / 8;
+    constexpr int P8 = (NSL + 7) / 8;
     f32x4 fin8[P8];
     auto exchange8 = [&](auto me_) {
       constexpr int ME = decltype(me_)::value;
@@ -478,6 +479,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       }
       __syncthreads();
       STAMP(22);
+      if constexpr (ME >= NSL) return;  // (owns nothing)
       // inbox f of owner ME holds the copy of wave (ME + 1 + f) & 7: all reads first, then the sums in wave order
       f32x4 got[P8][7];
 #pragma unroll
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(64 * KW) gemm_wide_kernel(int n_slices, int m_
       case 6: exchange8(Flag<6>{}); break;
       default: exchange8(Flag<7>{}); break;
     }
+    if (w >= NSL) return;  // (four slices: the upper waves own nothing)
 #pragma unroll
     for (int j = 0; j < P8; ++j) {
       const int tm = 2 * j + (w >> 2), q = w & 3;  // slice 8 j + w = (tile tm, register group q)
@@ -664,7 +667,7 @@ int launch_wide(const GemmArgs& a, hipStream_t s, int batch, bool act, int split
   constexpr int per = wide_slices_per_owner(MT, T, true);  // (the larger of the two epilogues' inbox sizes)
   constexpr int inbox = 12 * per * 1024 + 16;               // 4 owners x 3 senders, then the ticket word
   constexpr int park = KW > 4 ? 4 * T * MT * 4 * 1024 : 0;  // 8 waves: the upper four park whole partial tiles first
-  constexpr int direct8 = KW == 8 && (T * MT * 4) % 8 == 0 ? 56 * (T * MT * 4 / 8) * 1024 : 0;  // or: 8 owners x 7 senders
+  constexpr int direct8 = KW == 8 && ((T * MT * 4) % 8 == 0 || T * MT == 1) ? 56 * ((T * MT * 4 + 7) / 8) * 1024 : 0;  // or: 8 owners x 7 senders
   constexpr int reduce0 = park > inbox ? park : inbox;
   constexpr int reduce = direct8 > reduce0 && direct8 <= 160 * 1024 ? direct8 : reduce0;
   constexpr int lds = stage > reduce ? stage : reduce;
