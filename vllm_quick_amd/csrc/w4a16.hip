@@ -89,9 +89,10 @@ struct Choice {
 // shapes x 14 layer shapes (Llama-2-7B, Llama-2-70B as one of 8 ranks, Mixtral, 2/4/8-way shards of the
 // benchmark layer) x 17-4096 rows (scripts/exp_shared_sweep.py), then each shape's pair scaled by a common factor
 // where that lowers the loss of the CHOICE (scripts/fit_chooser.py --tune; whole rounds of 256
-// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.4 %
-// on two sweeps of the current kernels (448 cases); with each layer shape held out of fit and tuning in turn, 0.6 %
-// (worst 17 %).  The 32-row x 32-column private-slab shape <1,1,8> is what narrow layers take up to 64 rows: 128
+// undervalue the 4-wave 128 x 256 shape, two of which share a CU): mean loss against the best built shape 0.2 %
+// on two sweeps of the current kernels (448 cases, every layer's weights rotated over 640 MB so that they come
+// from HBM, not from the 256 MB memory-side cache); with each layer shape held out of fit and tuning in turn, 0.4 %
+// (worst 29 %).  The 32-row x 32-column private-slab shape <1,1,8> is what narrow layers take up to 64 rows: 128
 // column slices of a 4096-column layer x 2 row blocks fill the chip, where 64-column slices leave half of it idle
 // (11008 x 4096 at 33 / 64 rows 12.1 / 13.6 us against 15.9 / 15.9; 8192 x 1280 at 17-128 rows 8.4-9.5 against 12.0).  The private-slab kernel splits K
 // over the waves of a workgroup, so it keeps many workgroups on narrow layers at any row count (8192 x 1280 at
@@ -103,11 +104,11 @@ Choice choose_mfma32(int M, int K, int N, int batch, bool have_ws = false) {
     double a, b;
   };
   static const Shape shapes[] = {
-      {1, 1, 1, 8, 0.1175, 0.866}, {1, 2, 1, 8, 0.1505, 1.336}, {1, 3, 1, 4, 0.2508, 1.701}, {1, 3, 1, 8, 0.2334, 3.177},
-      {2, 1, 1, 8, 0.1846, 2.179}, {2, 2, 1, 4, 0.2058, 3.005}, {2, 2, 1, 8, 0.2260, 3.757}, {2, 3, 1, 4, 0.2880, 4.288},
-      {2, 3, 1, 8, 0.2787, 5.340}, {4, 3, 1, 4, 0.4897, 7.834}, {2, 1, 8, 1, 0.6417, 2.984}, {2, 2, 8, 1, 1.2501, 4.449},
-      {2, 3, 8, 1, 1.7864, 5.184}, {4, 1, 8, 1, 1.1968, 3.974}, {4, 2, 4, 1, 1.1510, 3.847}, {4, 2, 8, 1, 2.2194, 5.541},
-      {4, 3, 4, 1, 1.6579, 6.125}};
+      {1, 1, 1, 8, 0.1245, 0.841}, {1, 2, 1, 8, 0.1751, 1.409}, {1, 3, 1, 4, 0.2302, 1.474}, {1, 3, 1, 8, 0.2046, 2.528},
+      {2, 1, 1, 8, 0.2029, 2.183}, {2, 2, 1, 4, 0.2452, 2.968}, {2, 2, 1, 8, 0.2565, 3.395}, {2, 3, 1, 4, 0.2773, 3.642},
+      {2, 3, 1, 8, 0.3107, 4.965}, {4, 3, 1, 4, 0.4608, 6.605}, {2, 1, 8, 1, 0.7621, 3.621}, {2, 2, 8, 1, 1.2463, 4.535},
+      {2, 3, 8, 1, 1.7787, 5.336}, {4, 1, 8, 1, 1.1983, 3.983}, {4, 2, 4, 1, 1.0892, 3.330}, {4, 2, 8, 1, 2.0759, 5.227},
+      {4, 3, 4, 1, 1.6615, 5.793}};
   Choice best{true, 2, 3, 1, -4};
   double best_cost = 1e300;
   for (const Shape& c : shapes) {
